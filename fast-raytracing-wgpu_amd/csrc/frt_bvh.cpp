@@ -1,0 +1,210 @@
+// frt_bvh.cpp — host SAH-BVH over the flattened triangle list. Replaces the driver BLAS/TLAS build hidden behind
+// wgpu's EXPERIMENTAL_RAY_QUERY (src/geometry.rs:35-44, src/scene/builder.rs:143-179, :454-468).
+//
+// Output 1: canonical BVH2 (frt_bvh2_node, 32 B) — binned SAH (16 bins, 3 axes), leaves <= 4 triangles, deterministic
+//           (stable partitions, ties broken by triangle id); depth capped at kMaxBvhDepth by switching to median splits.
+// Output 2: GPU layout — 64-byte pair nodes (both child boxes in the parent) + 48-byte triangle slots in leaf order.
+// Boxes are padded so that box tests are strictly more permissive than the ray/triangle test (hit semantics do not
+// depend on the tree: DESIGN.md §3).
+#include "frt_scene.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace frt {
+
+namespace {
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -lo[a]; } }
+    void grow(const float p[3]) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    void grow(const Box& b) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+struct Prim { Box box; float centroid[3]; uint32_t id; };
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<frt_bvh2_node>& nodes;
+    uint32_t max_depth = 0, leaves = 0, max_leaf = 0;
+    float pad;
+    explicit Builder(std::vector<frt_bvh2_node>& n) : nodes(n) {}
+
+    void set_node_box(uint32_t ni, const Box& b) {
+        for (int a = 0; a < 3; ++a) { nodes[ni].bmin[a] = b.lo[a] - pad; nodes[ni].bmax[a] = b.hi[a] + pad; }
+    }
+    static int ceil_log2(uint32_t n) { int l = 0; while ((1u << l) < n) ++l; return l; }
+
+    void build(uint32_t ni, uint32_t first, uint32_t count, uint32_t depth) {
+        max_depth = std::max(max_depth, depth);
+        Box box, cbox;
+        box.reset(); cbox.reset();
+        for (uint32_t i = first; i < first + count; ++i) { box.grow(prims[i].box); cbox.grow(prims[i].centroid); }
+        set_node_box(ni, box);
+        const uint32_t kLeaf = 4;
+        if (count <= kLeaf) {
+            nodes[ni].left_first = first; nodes[ni].count = count;
+            ++leaves; max_leaf = std::max(max_leaf, count);
+            return;
+        }
+        uint32_t mid = 0;
+        // depth budget: a balanced finish needs ceil(log2(count / 1)) more levels at most
+        bool force_median = (int)depth + ceil_log2(count) + 1 >= kMaxBvhDepth;
+        int best_axis = -1;
+        if (!force_median) {
+            const int kBins = 16;
+            float best_cost = std::numeric_limits<float>::infinity();
+            int best_split = -1;
+            for (int axis = 0; axis < 3; ++axis) {
+                float lo = cbox.lo[axis], ext = cbox.hi[axis] - lo;
+                if (!(ext > 0.0f)) continue;
+                Box bb[kBins]; uint32_t bn[kBins];
+                for (int b = 0; b < kBins; ++b) { bb[b].reset(); bn[b] = 0; }
+                float scale = (float)kBins / ext;
+                for (uint32_t i = first; i < first + count; ++i) {
+                    int b = std::min(kBins - 1, (int)((prims[i].centroid[axis] - lo) * scale));
+                    bb[b].grow(prims[i].box); ++bn[b];
+                }
+                float right_area[kBins]; uint32_t right_n[kBins];
+                Box acc; acc.reset(); uint32_t n = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); n += bn[b]; right_area[b] = acc.half_area(); right_n[b] = n; }
+                acc.reset(); n = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(bb[b]); n += bn[b];
+                    if (n == 0 || right_n[b + 1] == 0) continue;
+                    float cost = acc.half_area() * (float)n + right_area[b + 1] * (float)right_n[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                float lo = cbox.lo[best_axis], scale = 16.0f / (cbox.hi[best_axis] - lo);
+                auto it = std::stable_partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim& p) {
+                    int b = std::min(15, (int)((p.centroid[best_axis] - lo) * scale));
+                    return b <= best_split;
+                });
+                mid = (uint32_t)(it - prims.begin());
+            }
+        }
+        if (best_axis < 0 || mid == first || mid == first + count) {
+            // median split on the widest centroid axis (ties / degenerate input / depth budget), order by (centroid, id)
+            int axis = 0;
+            float e0 = cbox.hi[0] - cbox.lo[0], e1 = cbox.hi[1] - cbox.lo[1], e2 = cbox.hi[2] - cbox.lo[2];
+            if (e1 > e0 && e1 >= e2) axis = 1; else if (e2 > e0 && e2 > e1) axis = 2;
+            mid = first + count / 2;
+            std::sort(prims.begin() + first, prims.begin() + first + count, [&](const Prim& a, const Prim& b) {
+                if (a.centroid[axis] != b.centroid[axis]) return a.centroid[axis] < b.centroid[axis];
+                return a.id < b.id;
+            });
+        }
+        uint32_t left = (uint32_t)nodes.size();
+        nodes.push_back(frt_bvh2_node{}); nodes.push_back(frt_bvh2_node{});
+        nodes[ni].left_first = left; nodes[ni].count = 0;
+        build(left, first, mid - first, depth + 1);
+        build(left + 1, mid, first + count - mid, depth + 1);
+    }
+};
+} // namespace
+
+void SceneBuilder::build_bvh2() {
+    bvh2.clear(); bvh2_tri_index.clear();
+    bvh_depth = bvh_leaves = bvh_max_leaf = 0;
+    if (tris.empty()) { error = "scene has no triangles"; return; }
+    if (tris.size() >= (1u << 24)) { error = "more than 2^24 triangles"; return; }
+    Builder b(bvh2);
+    b.prims.resize(tris.size());
+    Box scene_box; scene_box.reset();
+    for (size_t i = 0; i < tris.size(); ++i) {
+        const TriRec& t = tris[i];
+        Prim& p = b.prims[i];
+        // bounds of the triangle the intersector actually sees: v0, v0 + e1, v0 + e2
+        float v1[3], v2[3];
+        for (int a = 0; a < 3; ++a) { v1[a] = t.v0[a] + t.e1[a]; v2[a] = t.v0[a] + t.e2[a]; }
+        p.box.reset(); p.box.grow(t.v0); p.box.grow(v1); p.box.grow(v2);
+        for (int a = 0; a < 3; ++a) p.centroid[a] = 0.5f * (p.box.lo[a] + p.box.hi[a]);
+        p.id = (uint32_t)i;
+        scene_box.grow(p.box);
+    }
+    float ext = 0.0f;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, std::max(fabsf(scene_box.lo[a]), fabsf(scene_box.hi[a])));
+    b.pad = 1e-4f * std::max(ext, 1.0f);
+    bvh2.reserve(tris.size() * 2);
+    bvh2.push_back(frt_bvh2_node{});
+    b.build(0, 0, (uint32_t)tris.size(), 1);
+    bvh2_tri_index.resize(tris.size());
+    for (size_t i = 0; i < tris.size(); ++i) bvh2_tri_index[i] = b.prims[i].id;
+    bvh_depth = b.max_depth; bvh_leaves = b.leaves; bvh_max_leaf = b.max_leaf;
+    if ((int)bvh_depth > kMaxBvhDepth) error = "BVH depth exceeds the traversal stack";
+}
+
+void SceneBuilder::build_gpu_layout() {
+    pair_nodes.clear(); tri_slots.clear(); instances_dev.clear();
+    if (!error.empty()) return;
+    // triangle slots in leaf (bvh2_tri_index) order
+    tri_slots.resize(tris.size());
+    for (size_t s = 0; s < tris.size(); ++s) {
+        uint32_t id = bvh2_tri_index[s];
+        const TriRec& t = tris[id];
+        TriSlot& o = tri_slots[s];
+        uint32_t inst = tri_instance[id];
+        float idf, instf;
+        memcpy(&idf, &id, 4); memcpy(&instf, &inst, 4);
+        o.q[0] = t.v0[0]; o.q[1] = t.v0[1]; o.q[2] = t.v0[2]; o.q[3] = idf;
+        o.q[4] = t.e1[0]; o.q[5] = t.e1[1]; o.q[6] = t.e1[2]; o.q[7] = instf;
+        o.q[8] = t.e2[0]; o.q[9] = t.e2[1]; o.q[10] = t.e2[2]; o.q[11] = 0.0f;
+    }
+    // pair nodes: one per BVH2 inner node (a lone leaf root becomes a pair with an absent second child)
+    std::vector<uint32_t> pair_of(bvh2.size(), kNoChild);
+    auto ref_of = [&](uint32_t ni) -> uint32_t {
+        const frt_bvh2_node& n = bvh2[ni];
+        if (n.count > 0) return kLeafFlag | (n.count << 24) | n.left_first;
+        return pair_of[ni];
+    };
+    // assign pair indices in BFS order so the top of the tree is contiguous at the front
+    std::vector<uint32_t> order;
+    if (bvh2[0].count == 0) {
+        order.push_back(0);
+        for (size_t h = 0; h < order.size(); ++h) {
+            const frt_bvh2_node& n = bvh2[order[h]];
+            for (uint32_t c = n.left_first; c < n.left_first + 2; ++c)
+                if (bvh2[c].count == 0) order.push_back(c);
+        }
+        for (size_t i = 0; i < order.size(); ++i) pair_of[order[i]] = (uint32_t)i;
+    }
+    auto put_box = [](PairNode& p, int child, const frt_bvh2_node* n) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = n ? n->bmin[a] : std::numeric_limits<float>::infinity();
+            hi[a] = n ? n->bmax[a] : -std::numeric_limits<float>::infinity();
+        }
+        if (child == 0) { p.q[0] = lo[0]; p.q[1] = lo[1]; p.q[2] = lo[2]; p.q[3] = hi[0]; p.q[4] = hi[1]; p.q[5] = hi[2]; }
+        else { p.q[6] = lo[0]; p.q[7] = lo[1]; p.q[8] = lo[2]; p.q[9] = hi[0]; p.q[10] = hi[1]; p.q[11] = hi[2]; }
+    };
+    auto put_ref = [](PairNode& p, int child, uint32_t ref) { memcpy(&p.q[12 + child], &ref, 4); };
+    if (order.empty()) {
+        PairNode p{};
+        put_box(p, 0, &bvh2[0]); put_ref(p, 0, ref_of(0));
+        put_box(p, 1, nullptr); put_ref(p, 1, kNoChild);
+        pair_nodes.push_back(p);
+    } else {
+        pair_nodes.resize(order.size());
+        for (size_t i = 0; i < order.size(); ++i) {
+            const frt_bvh2_node& n = bvh2[order[i]];
+            PairNode p{};
+            for (int c = 0; c < 2; ++c) { put_box(p, c, &bvh2[n.left_first + c]); put_ref(p, c, ref_of(n.left_first + c)); }
+            pair_nodes[i] = p;
+        }
+    }
+    instances_dev.resize(instances.size());
+    for (size_t i = 0; i < instances.size(); ++i) {
+        InstanceDev& d = instances_dev[i];
+        memset(&d, 0, sizeof(d));
+        d.mesh_id = instances[i].mesh_id; d.mat_id = instances[i].mat_id; d.first_tri = instances[i].first_tri; d.flip = instances[i].flip;
+        memcpy(d.w2o, instances[i].w2o, sizeof(d.w2o));
+    }
+}
+
+} // namespace frt

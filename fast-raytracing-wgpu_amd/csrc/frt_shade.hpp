@@ -1,0 +1,832 @@
+// frt_shade.hpp — device functions of the shading path: BSDF (GGX-VNDF + Lambert + delta glass), light sampling,
+// NEE with MIS, Russian roulette, trace_path in both of the reference's variants, and the per-pixel bodies of the four
+// stages (gbuffer.wgsl, restir.wgsl, restir_spatial.wgsl, post.wgsl). Contract arithmetic throughout (frt_math.hpp).
+// __host__ __device__ so that tests/hostcheck can instantiate the same functions on the CPU; the library only ever
+// launches them from kernels (frt_kernels.hip).
+#pragma once
+#include "frt_trace.hpp"
+
+namespace frt {
+
+struct ReservoirView { uint32_t y; float w_sum; uint32_t M; float W; float sx, sy, sz; float p_hat; };   // restir.rs:5-14
+
+struct CameraView {   // camera.rs:4-15 (288 B)
+    float view_proj[16], view_inverse[16], proj_inverse[16], view_pos[4], prev_view_proj[16];
+    uint32_t frame_count, num_lights, pad0, pad1;
+};
+
+// Per-frame view of the per-pixel buffers in HBM. Full-frame pitch; a launch covers rows [y0, y1).
+struct FrameView {
+    float4* gpos; float4* gnormal; uint32_t* galbedo;                     // current G-buffer slot (frame_count % 2)
+    const float4* gpos_prev; const float4* gnormal_prev; const uint32_t* galbedo_prev;
+    float2* gmotion;
+    ReservoirView* res_temporal;     // reservoir_buffers[0]
+    ReservoirView* res_spatial;      // reservoir_buffers[1]
+    uint2* raw;                      // rgba16f
+    uint32_t* display;               // rgba8
+    const float4* history; float4* accum;
+    unsigned long long* ray_counters;   // [0] closest, [1] any
+    uint32_t W, H, frame_count, max_depth, y0, y1;
+    uint32_t own_y0, own_y1;         // rows whose rays are counted (a strip's redundant halo rows are not)
+    CameraView cam;
+};
+
+static constexpr float kPI = 3.14159265359f;   // restir.wgsl:4
+
+struct PathCtx {
+    const SceneView& sc;
+    const FrameView& fv;
+    uint32_t* stk; uint32_t stride;
+    uint32_t rng;               // var<private> rng_seed, restir.wgsl:130
+    uint32_t n_closest, n_any;  // rays issued by this lane
+    FRT_HD PathCtx(const SceneView& s, const FrameView& f, uint32_t* st, uint32_t sd) : sc(s), fv(f), stk(st), stride(sd), rng(0), n_closest(0), n_any(0) {}
+    FRT_HD float rand() { rng = pcg_hash(rng); return (float)rng / 4294967296.0f; }   // restir.wgsl:138-141 (literal rounds to 2^32)
+};
+
+FRT_HD float rand_lcg(uint32_t& state) {   // restir.wgsl:781-786
+    uint32_t old = state;
+    state = old * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (float)((word >> 22u) ^ word) / 4294967296.0f;
+}
+FRT_HD float luminance(f3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }   // restir.wgsl:742
+
+// ------------------------------------------------------------------------------------------------ textures
+// textureSampleLevel(level 0) under the sampler of renderer.rs:240-249 (Repeat / Linear): f32 bilinear on texel centres.
+template <bool SRGB>
+FRT_HD f4 fetch_texel(const SceneView& sc, const uint8_t* base, int x, int y) {
+    uint32_t p = reinterpret_cast<const uint32_t*>(base)[(uint32_t)y * 1024u + (uint32_t)x];
+    uint32_t r = p & 0xffu, g = (p >> 8) & 0xffu, b = (p >> 16) & 0xffu, a = p >> 24;
+    if (SRGB) return mk4(sc.srgb_lut[r], sc.srgb_lut[g], sc.srgb_lut[b], (float)a / 255.0f);
+    return mk4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f);
+}
+template <bool SRGB>
+FRT_HD f4 sample_layer(const SceneView& sc, uint32_t layer, f2 uv) {
+    const uint8_t* base = (SRGB ? sc.color_tex : sc.data_tex) + (size_t)layer * (1024u * 1024u * 4u);
+    float x = uv.x * 1024.0f - 0.5f, y = uv.y * 1024.0f - 0.5f;
+    float fx = floorf_(x), fy = floorf_(y);
+    float ax = x - fx, ay = y - fy;
+    int x0 = (int)fx & 1023, y0 = (int)fy & 1023, x1 = (x0 + 1) & 1023, y1 = (y0 + 1) & 1023;
+    f4 t00 = fetch_texel<SRGB>(sc, base, x0, y0), t10 = fetch_texel<SRGB>(sc, base, x1, y0);
+    f4 t01 = fetch_texel<SRGB>(sc, base, x0, y1), t11 = fetch_texel<SRGB>(sc, base, x1, y1);
+    f4 top = t00 * (1.0f - ax) + t10 * ax;
+    f4 bot = t01 * (1.0f - ax) + t11 * ax;
+    return top * (1.0f - ay) + bot * ay;
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+FRT_HD f3 decode_octahedral_normal(float ex, float ey) {   // gbuffer.wgsl:38-44
+    f3 n = mk3(ex, ey, 1.0f - fabsf_(ex) - fabsf_(ey));
+    float t = fmaxn(-n.z, 0.0f);
+    n.x += (n.x >= 0.0f) ? -t : t;
+    n.y += (n.y >= 0.0f) ? -t : t;
+    return normalize(n);
+}
+FRT_HD f2 encode_octahedral_normal(f3 n) {   // gbuffer.wgsl:46-62
+    float l1 = fabsf_(n.x) + fabsf_(n.y) + fabsf_(n.z);
+    float s = 1.0f / fmaxn(l1, 1e-6f);
+    f2 res = l1 > 0.0f ? mk2(n.x * s, n.y * s) : mk2(0.0f, 0.0f);
+    if (n.z < 0.0f) {
+        float sx = res.x >= 0.0f ? 1.0f : -1.0f, sy = res.y >= 0.0f ? 1.0f : -1.0f;
+        return mk2((1.0f - fabsf_(res.y)) * sx, (1.0f - fabsf_(res.x)) * sy);
+    }
+    return res;
+}
+FRT_HD void make_orthonormal_basis(f3 n, f3& tangent, f3& bitangent) {   // restir.wgsl:161-168
+    float sign = n.z >= 0.0f ? 1.0f : -1.0f;
+    float a = -1.0f / (sign + n.z);
+    float b = n.x * n.y * a;
+    tangent = mk3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+    bitangent = mk3(b, sign + n.y * n.y * a, -n.y);
+}
+FRT_HD f3 fresnel_schlick(f3 f0, float v_dot_h) {   // :170
+    return f0 + (1.0f - f0) * powf_(clampf(1.0f - v_dot_h, 0.0f, 1.0f), 5.0f);
+}
+FRT_HD float reflectance(float cosine, float ref_idx) {   // :175
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * powf_(1.0f - cosine, 5.0f);
+}
+FRT_HD float ndf_ggx(float n_dot_h, float roughness) {   // :182
+    float a = roughness * roughness;
+    float a2 = a * a;
+    float d = n_dot_h * n_dot_h * (a2 - 1.0f) + 1.0f;
+    return a2 / (kPI * d * d);
+}
+FRT_HD float geometry_schlick_ggx(float n_dot_v, float roughness) {   // :189
+    float a2 = roughness * roughness;
+    return 2.0f * n_dot_v / (n_dot_v + sqrtf_(a2 + (1.0f - a2) * n_dot_v * n_dot_v));
+}
+FRT_HD float geometry_smith(float n_dot_l, float n_dot_v, float roughness) {
+    return geometry_schlick_ggx(n_dot_l, roughness) * geometry_schlick_ggx(n_dot_v, roughness);
+}
+FRT_HD f3 sample_ggx_vndf(f3 wo, float roughness, float ux, float uy) {   // :202-216
+    float alpha = roughness * roughness;
+    f3 Vh = normalize(mk3(alpha * wo.x, alpha * wo.y, wo.z));
+    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    f3 T1 = lensq > 0.0f ? mk3(-Vh.y, Vh.x, 0.0f) * rsqrt_exact(lensq) : mk3(1.0f, 0.0f, 0.0f);
+    f3 T2 = cross(Vh, T1);
+    float r = sqrtf_(ux);
+    float phi = 2.0f * kPI * uy;
+    float sphi, cphi;
+    sincosf_(phi, sphi, cphi);
+    float t1 = r * cphi;
+    float t2 = r * sphi;
+    float s = 0.5f * (1.0f + Vh.z);
+    float t2l = (1.0f - s) * sqrtf_(1.0f - t1 * t1) + s * t2;
+    f3 Nh = t1 * T1 + t2l * T2 + sqrtf_(fmaxn(0.0f, 1.0f - t1 * t1 - t2l * t2l)) * Vh;
+    return normalize(mk3(alpha * Nh.x, alpha * Nh.y, fmaxn(0.0f, Nh.z)));
+}
+
+struct MatParams {   // the fields of `mat` the BSDF code reads
+    float roughness, metallic, transmission, ior;
+};
+struct Surf {        // HitInfo subset, restir.wgsl:81-90
+    f3 pos, normal, ffnormal; f2 uv; bool front_face; float t; f4 tangent; uint32_t mat_id;
+};
+struct LightSmp { f3 pos, normal; float pdf; f4 emission; };
+struct BsdfSmp { f3 wi; float pdf; f3 weight; };
+
+FRT_HD LightSmp sample_light(PathCtx& c, uint32_t light_idx) {   // :219-245
+    const LightView& L = c.sc.lights[light_idx];
+    LightSmp s;
+    s.emission = mk4(L.emission[0], L.emission[1], L.emission[2], L.emission[3]);
+    float r1 = c.rand();
+    float r2 = c.rand();
+    f3 lp = mk3(L.position[0], L.position[1], L.position[2]);
+    if (L.type_ == 0u) {
+        f3 lu = mk3(L.u[0], L.u[1], L.u[2]), lv = mk3(L.v[0], L.v[1], L.v[2]);
+        float su = r1 * 2.0f - 1.0f;
+        float sv = r2 * 2.0f - 1.0f;
+        s.pos = lp + lu * su + lv * sv;
+        s.normal = normalize(cross(lu, lv));
+        s.pdf = 1.0f / L.area;
+    } else {
+        float z = 1.0f - 2.0f * r1;
+        float r_xy = sqrtf_(fmaxn(0.0f, 1.0f - z * z));
+        float phi = 2.0f * kPI * r2;
+        float sp, cp;
+        sincosf_(phi, sp, cp);
+        f3 local_dir = mk3(r_xy * cp, r_xy * sp, z);
+        s.pos = lp + local_dir * L.v[0];
+        s.normal = local_dir;
+        s.pdf = 1.0f / L.area;
+    }
+    return s;
+}
+FRT_HD float eval_pdf(f3 normal, f3 wi, f3 wo, const MatParams& m, f3 base_color) {   // :249-276
+    float n_dot_l = dot(normal, wi);
+    float n_dot_v = dot(normal, wo);
+    if (m.transmission > 0.01f) return 0.0f;
+    if (n_dot_l <= 0.0f || n_dot_v <= 0.0f) return 0.0f;
+    f3 F0 = mix3(splat3(0.04f), base_color, m.metallic);
+    f3 F = fresnel_schlick(F0, fmaxn(dot(normal, wo), 0.0f));
+    float lum_spec = luminance(F);
+    float lum_diff = luminance(base_color * (1.0f - m.metallic));
+    float prob_spec = clampf(lum_spec / (lum_spec + lum_diff + 0.0001f), 0.001f, 0.999f);
+    f3 h = normalize(wi + wo);
+    float n_dot_h = fmaxn(dot(normal, h), 0.0f);
+    float d = ndf_ggx(n_dot_h, m.roughness);
+    float g1 = geometry_schlick_ggx(n_dot_v, m.roughness);
+    float pdf_spec = (d * g1) / (4.0f * n_dot_v);
+    float pdf_diff = fmaxn(n_dot_l, 0.0f) / kPI;
+    return prob_spec * pdf_spec + (1.0f - prob_spec) * pdf_diff;
+}
+FRT_HD f3 eval_bsdf(f3 normal, f3 wi, f3 wo, const MatParams& m, f3 base_color) {   // :278-305
+    float n_dot_l = dot(normal, wi);
+    float n_dot_v = dot(normal, wo);
+    if (m.transmission > 0.01f) return splat3(0.0f);
+    if (n_dot_l <= 0.0f || n_dot_v <= 0.0f) return splat3(0.0f);
+    f3 h = normalize(wi + wo);
+    float n_dot_h = fmaxn(dot(normal, h), 0.0f);
+    float h_dot_v = fmaxn(dot(h, wo), 0.0f);
+    f3 F0 = mix3(splat3(0.04f), base_color, m.metallic);
+    float D = ndf_ggx(n_dot_h, m.roughness);
+    float G = geometry_smith(n_dot_l, n_dot_v, m.roughness);
+    f3 F = fresnel_schlick(F0, h_dot_v);
+    f3 specular = (D * G * F) / fmaxn(4.0f * n_dot_l * n_dot_v, 0.001f);
+    f3 kD = (splat3(1.0f) - F) * (1.0f - m.metallic);
+    f3 diffuse = kD * base_color / kPI;
+    return diffuse + specular;
+}
+FRT_HD f3 random_unit_vector(PathCtx& c) {   // :143-150
+    float z = c.rand() * 2.0f - 1.0f;
+    float a = c.rand() * 2.0f * kPI;
+    float r = sqrtf_(1.0f - z * z);
+    float sa, ca;
+    sincosf_(a, sa, ca);
+    return mk3(r * ca, r * sa, z);
+}
+FRT_HD BsdfSmp sample_bsdf(PathCtx& c, f3 wo, const Surf& hit, const MatParams& m, f3 base_color) {   // :307-371
+    BsdfSmp s;
+    if (m.transmission > 0.01f) {
+        s.pdf = 0.0f;
+        float refraction_ratio = hit.front_face ? 1.0f / m.ior : m.ior;
+        float cos_theta = fminn(dot(wo, hit.ffnormal), 1.0f);
+        float sin_theta = sqrtf_(1.0f - cos_theta * cos_theta);
+        bool refl = refraction_ratio * sin_theta > 1.0f;
+        if (!refl) refl = reflectance(cos_theta, refraction_ratio) > c.rand();   // short-circuit ||, :318
+        s.wi = refl ? reflect(-wo, hit.ffnormal) : refract(-wo, hit.ffnormal, refraction_ratio);
+        s.weight = base_color;
+        return s;
+    }
+    f3 F0 = mix3(splat3(0.04f), base_color, m.metallic);
+    f3 F_view = fresnel_schlick(F0, fmaxn(dot(hit.ffnormal, wo), 0.0f));
+    float lum_spec = luminance(F_view);
+    float lum_diff = luminance(base_color * (1.0f - m.metallic));
+    float prob_spec = clampf(lum_spec / (lum_spec + lum_diff + 0.0001f), 0.001f, 0.999f);
+    float rnd = c.rand();
+    if (rnd < prob_spec) {
+        f3 tb, bt, n = hit.ffnormal;
+        make_orthonormal_basis(n, tb, bt);
+        f3 wo_local = mk3(dot(tb, wo), dot(bt, wo), dot(n, wo));
+        float ru = c.rand();
+        float rv = c.rand();
+        f3 wm_local = sample_ggx_vndf(wo_local, m.roughness, ru, rv);
+        f3 wm = tb * wm_local.x + bt * wm_local.y + n * wm_local.z;
+        s.wi = reflect(-wo, wm);
+    } else {
+        s.wi = normalize(hit.ffnormal + random_unit_vector(c));
+    }
+    float n_dot_l = dot(hit.ffnormal, s.wi);
+    float n_dot_v = dot(hit.ffnormal, wo);
+    if (n_dot_l <= 0.0f || n_dot_v <= 0.0f) { s.weight = splat3(0.0f); s.pdf = 0.0f; return s; }
+    f3 bsdf_val = eval_bsdf(hit.ffnormal, s.wi, wo, m, base_color);
+    s.pdf = eval_pdf(hit.ffnormal, s.wi, wo, m, base_color);
+    if (s.pdf > 0.0f) s.weight = bsdf_val * n_dot_l / s.pdf;
+    else s.weight = splat3(0.0f);
+    return s;
+}
+
+// restir.wgsl:375-381 (VARIANT 0) vs restir_spatial.wgsl:380-400 (VARIANT 1). true = unoccluded.
+template <int VARIANT>
+FRT_HD bool trace_shadow_ray(PathCtx& c, f3 origin, f3 dir, float dist) {
+    float t_max = fmaxn(dist * 0.999f, 0.0f);
+    float t_min = VARIANT == 0 ? 0.001f : 0.0001f;
+    if (VARIANT == 1 && t_min >= t_max) return true;
+    HitRec h;
+    c.n_any++;
+    trace<true>(c.sc, origin, dir, t_min, t_max, c.stk, c.stride, h);
+    return h.tri == 0xFFFFFFFFu;
+}
+
+// Attribute fetch + interpolation for a committed hit: gbuffer.wgsl:124-174 and restir.wgsl:383-441
+struct HitGeom { f3 normal_w, tangent_w; f2 uv; float tangent_sign; uint32_t mat_id; };
+FRT_HD HitGeom fetch_hit_geometry(const SceneView& sc, const HitRec& h) {
+    const InstanceView& in = sc.instances[h.inst];
+    uint32_t prim = h.tri - in.first_tri;
+    MeshInfoView mi = sc.mesh_infos[in.mesh_id];
+    uint32_t io = mi.index_offset + prim * 3u;
+    uint32_t i0 = sc.indices[io + 0u] + mi.vertex_offset;
+    uint32_t i1 = sc.indices[io + 1u] + mi.vertex_offset;
+    uint32_t i2 = sc.indices[io + 2u] + mi.vertex_offset;
+    const VertexAttrView &a0 = sc.attributes[i0], &a1 = sc.attributes[i1], &a2 = sc.attributes[i2];
+    f3 n0 = decode_octahedral_normal(a0.normal[0], a0.normal[1]);
+    f3 n1 = decode_octahedral_normal(a1.normal[0], a1.normal[1]);
+    f3 n2 = decode_octahedral_normal(a2.normal[0], a2.normal[1]);
+    f3 t0 = mk3(a0.tangent[0], a0.tangent[1], a0.tangent[2]);
+    f3 t1 = mk3(a1.tangent[0], a1.tangent[1], a1.tangent[2]);
+    f3 t2 = mk3(a2.tangent[0], a2.tangent[1], a2.tangent[2]);
+    float u = h.u, v = h.v, w = 1.0f - u - v;
+    f3 local_normal = normalize(n0 * w + n1 * u + n2 * v);
+    f3 local_tangent = normalize(t0 * w + t1 * u + t2 * v);
+    HitGeom g;
+    g.uv = mk2(a0.uv[0], a0.uv[1]) * w + mk2(a1.uv[0], a1.uv[1]) * u + mk2(a2.uv[0], a2.uv[1]) * v;
+    // v * mat3x3(w2o[0], w2o[1], w2o[2]) = (dot(v, col0), dot(v, col1), dot(v, col2))
+    f3 c0 = mk3(in.w2o[0], in.w2o[1], in.w2o[2]), c1 = mk3(in.w2o[3], in.w2o[4], in.w2o[5]), c2 = mk3(in.w2o[6], in.w2o[7], in.w2o[8]);
+    g.normal_w = normalize(mk3(dot(local_normal, c0), dot(local_normal, c1), dot(local_normal, c2)));
+    g.tangent_w = normalize(mk3(dot(local_tangent, c0), dot(local_tangent, c1), dot(local_tangent, c2)));
+    g.tangent_sign = a0.tangent[3];
+    g.mat_id = in.mat_id;
+    return g;
+}
+FRT_HD f3 perturb_normal(f3 N_ff, f3 tangent_w, float tangent_sign, f3 nm) {   // gbuffer.wgsl:206-219, restir.wgsl:657-671
+    f3 normal_local = normalize(nm * 2.0f - splat3(1.0f));
+    f3 T_ff = normalize(tangent_w - N_ff * dot(N_ff, tangent_w));
+    f3 B_ff = normalize(cross(N_ff, T_ff)) * tangent_sign;
+    return normalize(T_ff * normal_local.x + B_ff * normal_local.y + N_ff * normal_local.z);
+}
+
+template <int VARIANT>
+FRT_HD f3 eval_direct_lighting(PathCtx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_color, const LightSmp& ls, float weight) {   // :443-459
+    f3 offset_pos = hit.pos + hit.ffnormal * 0.001f;
+    f3 L = normalize(ls.pos - offset_pos);
+    float dist = distance(ls.pos, offset_pos);
+    float n_dot_l = fmaxn(dot(hit.ffnormal, L), 0.0f);
+    float l_dot_n = fmaxn(dot(-L, ls.normal), 0.0f);
+    if (n_dot_l > 0.0f && l_dot_n > 0.0f) {
+        if (trace_shadow_ray<VARIANT>(c, offset_pos, L, dist)) {
+            f3 f = eval_bsdf(hit.ffnormal, L, wo, m, base_color);
+            float G = (n_dot_l * l_dot_n) / (dist * dist);
+            return xyz(ls.emission) * ls.emission.w * f * G * weight;
+        }
+    }
+    return splat3(0.0f);
+}
+template <int VARIANT>
+FRT_HD f3 nee(PathCtx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_color, f3 throughput) {   // :558-571 == :707-720
+    uint32_t nl = c.fv.cam.num_lights;
+    if (nl > 0u) {
+        uint32_t light_idx = (uint32_t)(c.rand() * (float)nl);
+        if (light_idx < nl) {
+            LightSmp ls = sample_light(c, light_idx);
+            float pdf_nee = ls.pdf * (1.0f / (float)nl);
+            float p_bsdf = eval_pdf(hit.ffnormal, normalize(ls.pos - hit.pos), wo, m, base_color);
+            float mis_weight_nee = pdf_nee / (pdf_nee + p_bsdf);
+            float weight = mis_weight_nee / pdf_nee;
+            return eval_direct_lighting<VARIANT>(c, hit, wo, m, base_color, ls, weight) * throughput;
+        }
+    }
+    return splat3(0.0f);
+}
+
+struct PathOut { f3 radiance; f3 v1_pos; };
+
+// restir.wgsl:460-737 (VARIANT 0) / restir_spatial.wgsl:480-762 (VARIANT 1)
+template <int VARIANT>
+FRT_HD PathOut trace_path(PathCtx& c, uint32_t pix, uint32_t seed) {
+    const SceneView& sc = c.sc; const FrameView& fv = c.fv;
+    c.rng = seed;
+    PathOut out; out.radiance = splat3(0.0f); out.v1_pos = splat3(0.0f);
+    float4 pos_w = fv.gpos[pix];
+    if (pos_w.w < 0.0f) return out;
+    float4 normal_w = fv.gnormal[pix];
+    f4 albedo_raw = unpack_rgba8(fv.galbedo[pix]);
+
+    Surf hit;
+    hit.pos = mk3(pos_w.x, pos_w.y, pos_w.z);
+    hit.normal = decode_octahedral_normal(normal_w.x, normal_w.y);
+    hit.front_face = true;
+    hit.ffnormal = hit.normal;
+    hit.uv = mk2(normal_w.z, normal_w.w);
+    hit.t = 0.0f; hit.tangent = mk4(0, 0, 0, 0);
+
+    uint32_t mat_id = (uint32_t)(pos_w.w + 0.1f);
+    MatParams m; f3 base_color; f3 emissive_factor; int32_t light_index; uint32_t tex1, tex2;
+    if (mat_id < sc.num_materials) {
+        const MaterialView& ms = sc.materials[mat_id];
+        m.roughness = ms.roughness; m.metallic = ms.metallic; m.transmission = ms.transmission; m.ior = ms.ior;
+        light_index = ms.light_index; tex1 = ms.tex_info_1; tex2 = ms.tex_info_2;
+        emissive_factor = mk3(ms.emissive_factor[0], ms.emissive_factor[1], ms.emissive_factor[2]);
+        if (VARIANT == 0 || m.transmission < 0.01f) base_color = xyz(albedo_raw);     // restir.wgsl:494 vs restir_spatial.wgsl:514-516
+        else base_color = mk3(ms.base_color[0], ms.base_color[1], ms.base_color[2]);
+    } else {   // restir.wgsl:495-501: zero-initialised `var mat` with four fields set
+        m.roughness = 0.0f; m.metallic = albedo_raw.w; m.transmission = 0.0f; m.ior = 1.0f;
+        light_index = -1; tex1 = 0u; tex2 = 0u; emissive_factor = splat3(0.0f);
+        base_color = xyz(albedo_raw);
+    }
+    uint32_t mr_tex_id = tex2 & 0xFFFFu;
+    if (mr_tex_id != 65535u) {
+        f4 mr = sample_layer<false>(sc, mr_tex_id, hit.uv);
+        m.metallic = mr.z * m.metallic;
+        m.roughness = mr.y * m.roughness;
+    }
+    f3 accumulated = splat3(0.0f);
+    f3 throughput = splat3(1.0f);
+    f3 wo = normalize(mk3(fv.cam.view_pos[0], fv.cam.view_pos[1], fv.cam.view_pos[2]) - hit.pos);
+    uint32_t emissive_tex_id = tex1 >> 16u;
+
+    if (mat_id < sc.num_materials && light_index == -1) {   // :523-533
+        f3 emission = emissive_factor;
+        if (emissive_tex_id != 65535u) emission = emission * xyz(sample_layer<true>(sc, emissive_tex_id, hit.uv));
+        accumulated = accumulated + emission;
+    }
+    if (light_index >= 0) {   // :543-552
+        f3 emission = emissive_factor;
+        if (emissive_tex_id != 65535u) emission = emission * xyz(sample_layer<true>(sc, emissive_tex_id, hit.uv));
+        accumulated = accumulated + emission;
+        out.radiance = accumulated;
+        return out;
+    }
+    const bool is_glass = m.transmission > 0.01f;
+    bool previous_was_diffuse;
+    if (!(is_glass || m.roughness < 0.05f)) {   // :556
+        accumulated = accumulated + nee<VARIANT>(c, hit, wo, m, base_color, throughput);
+        previous_was_diffuse = true;
+    } else previous_was_diffuse = false;
+
+    BsdfSmp sc0 = sample_bsdf(c, wo, hit, m, base_color);
+    if (sc0.weight.x <= 0.0f && sc0.weight.y <= 0.0f && sc0.weight.z <= 0.0f) { out.radiance = accumulated; return out; }
+    float last_bsdf_pdf = sc0.pdf;
+    throughput = throughput * sc0.weight;
+    f3 next_dir = sc0.wi;
+
+    for (uint32_t depth = 1u; depth < fv.max_depth; depth++) {   // :590
+        if (depth >= 3u) {
+            float p = fmaxn(throughput.x, fmaxn(throughput.y, throughput.z));
+            float survival_prob = clampf(p, 0.05f, 0.95f);
+            if (c.rand() > survival_prob) break;
+            throughput = throughput / survival_prob;
+        }
+        f3 offset_dir = hit.ffnormal * signf(dot(hit.ffnormal, next_dir));
+        f3 origin = hit.pos + offset_dir * 0.001f;
+        HitRec h;
+        c.n_closest++;
+        trace<false>(sc, origin, next_dir, 0.001f, 100.0f, c.stk, c.stride, h);
+        if (h.tri == 0xFFFFFFFFu) break;
+        HitGeom g = fetch_hit_geometry(sc, h);   // reconstruct_geometry_hit, :383-441
+        hit.normal = g.normal_w;
+        hit.tangent = mk4(g.tangent_w, g.tangent_sign);
+        hit.uv = g.uv;
+        hit.front_face = h.front;
+        hit.ffnormal = h.front ? g.normal_w : -g.normal_w;
+        hit.t = h.t;
+        hit.pos = origin + next_dir * h.t;
+        hit.mat_id = g.mat_id;
+        if (depth == 1u) out.v1_pos = hit.pos;
+        wo = -next_dir;
+        const MaterialView& mb = sc.materials[hit.mat_id];
+        m.roughness = mb.roughness; m.metallic = mb.metallic; m.transmission = mb.transmission; m.ior = mb.ior;
+        int32_t light_index_b = mb.light_index;
+        uint32_t t0i = mb.tex_info_0, t1i = mb.tex_info_1;
+        f4 tex_color = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+        uint32_t tex_id = t0i & 0xFFFFu, normal_tex_id = t0i >> 16u;
+        if (tex_id != 65535u) tex_color = sample_layer<true>(sc, tex_id, hit.uv);
+        float occlusion = 1.0f;
+        uint32_t occlusion_tex_id = t1i & 0xFFFFu, emissive_tex_id_b = t1i >> 16u;
+        if (occlusion_tex_id != 65535u) occlusion = sample_layer<false>(sc, occlusion_tex_id, hit.uv).x;
+        base_color = mk3(mb.base_color[0], mb.base_color[1], mb.base_color[2]) * xyz(tex_color) * occlusion;
+        if (normal_tex_id != 65535u) {
+            f3 nm = xyz(sample_layer<false>(sc, normal_tex_id, hit.uv));
+            hit.ffnormal = perturb_normal(hit.ffnormal, xyz(hit.tangent), hit.tangent.w, nm);
+        }
+        if (light_index_b == -1 && emissive_tex_id_b != 65535u) {   // :675-678
+            f3 emissive_col = xyz(sample_layer<true>(sc, emissive_tex_id_b, hit.uv));
+            accumulated = accumulated + emissive_col * throughput;
+        }
+        if (light_index_b >= 0) {   // :683-700
+            if (hit.front_face) {
+                const LightView& light = sc.lights[light_index_b];
+                f3 Le = mk3(light.emission[0], light.emission[1], light.emission[2]) * light.emission[3];
+                float mis_weight = 1.0f;
+                if (previous_was_diffuse) {
+                    float dist_sq = hit.t * hit.t;
+                    float light_cos = fmaxn(dot(hit.ffnormal, -wo), 0.0f);
+                    float p_bsdf = last_bsdf_pdf;
+                    float p_nee = (1.0f / light.area) * (dist_sq / light_cos) * (1.0f / (float)fv.cam.num_lights);
+                    if (light_cos > 0.001f) mis_weight = p_bsdf / (p_bsdf + p_nee);
+                    else mis_weight = 0.0f;
+                }
+                accumulated = accumulated + Le * throughput * mis_weight;
+            }
+            break;
+        }
+        if (!(is_glass || m.roughness < 0.05f)) {   // :705 — the PRIMARY hit's is_glass (reference quirk)
+            accumulated = accumulated + nee<VARIANT>(c, hit, wo, m, base_color, throughput);
+            previous_was_diffuse = true;
+        } else previous_was_diffuse = false;
+        BsdfSmp sb = sample_bsdf(c, wo, hit, m, base_color);
+        if (sb.weight.x <= 0.0f && sb.weight.y <= 0.0f && sb.weight.z <= 0.0f) break;
+        last_bsdf_pdf = sb.pdf;
+        throughput = throughput * sb.weight;
+        next_dir = sb.wi;
+    }
+    out.radiance = accumulated;
+    return out;
+}
+
+FRT_HD void update_reservoir(ReservoirView& r, uint32_t seed_cand, float w, float rnd, uint32_t cnt, float p_hat_new, f3 s_path_new) {   // :746-756
+    r.w_sum += w;
+    r.M += cnt;
+    if (rnd * r.w_sum < w) { r.y = seed_cand; r.p_hat = p_hat_new; r.sx = s_path_new.x; r.sy = s_path_new.y; r.sz = s_path_new.z; }
+}
+FRT_HD ReservoirView zero_reservoir() { ReservoirView r; r.y = 0u; r.w_sum = 0.0f; r.M = 0u; r.W = 0.0f; r.sx = r.sy = r.sz = 0.0f; r.p_hat = 0.0f; return r; }
+
+// ================================================================================================ stage 0
+// gbuffer.wgsl:91-255
+FRT_HD void gbuffer_pixel(PathCtx& c, uint32_t px, uint32_t py) {
+    const SceneView& sc = c.sc; const FrameView& fv = c.fv;
+    uint32_t pix = py * fv.W + px;
+    f2 size = mk2((float)fv.W, (float)fv.H);
+    f2 uv = (mk2((float)px, (float)py) + mk2(0.5f, 0.5f)) / size;
+    f2 ndc = mk2(uv.x * 2.0f - 1.0f, 1.0f - uv.y * 2.0f);
+    m4 view_inv = load_m4(fv.cam.view_inverse), proj_inv = load_m4(fv.cam.proj_inverse);
+    f3 origin = xyz(view_inv.c[3]);
+    f4 target = mul(mul(view_inv, proj_inv), mk4(ndc.x, ndc.y, 1.0f, 1.0f));   // (view_inv * proj_inv) * v, :104
+    f3 direction = normalize(xyz(target) / target.w - origin);
+    HitRec h;
+    c.n_closest++;
+    trace<false>(sc, origin, direction, 0.001f, 1000.0f, c.stk, c.stride, h);
+    if (h.tri == 0xFFFFFFFFu) {
+        fv.gpos[pix] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        fv.gnormal[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        fv.galbedo[pix] = pack_rgba8(mk4(0.0f, 0.0f, 0.0f, 1.0f));
+        fv.gmotion[pix] = make_float2(0.0f, 0.0f);
+        return;
+    }
+    HitGeom g = fetch_hit_geometry(sc, h);
+    f3 ffnormal = h.front ? g.normal_w : -g.normal_w;
+    f3 pos = origin + direction * h.t;
+    const MaterialView& mat = sc.materials[g.mat_id];
+    f4 tex_color = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    uint32_t tex_id = mat.tex_info_0 & 0xFFFFu, normal_tex_id = mat.tex_info_0 >> 16u;
+    if (tex_id != 65535u) tex_color = sample_layer<true>(sc, tex_id, g.uv);
+    float occlusion = 1.0f;
+    uint32_t occlusion_tex_id = mat.tex_info_1 & 0xFFFFu;
+    if (occlusion_tex_id != 65535u) occlusion = sample_layer<false>(sc, occlusion_tex_id, g.uv).x;
+    f3 final_normal = ffnormal;
+    if (normal_tex_id != 65535u) {
+        f3 nm = xyz(sample_layer<false>(sc, normal_tex_id, g.uv));
+        final_normal = perturb_normal(ffnormal, g.tangent_w, g.tangent_sign, nm);
+    }
+    f3 base_color = mk3(mat.base_color[0], mat.base_color[1], mat.base_color[2]) * xyz(tex_color) * occlusion;
+    m4 view_proj = load_m4(fv.cam.view_proj), prev_view_proj = load_m4(fv.cam.prev_view_proj);
+    f4 curr_clip = mul(view_proj, mk4(pos, 1.0f));
+    f4 prev_clip = mul(prev_view_proj, mk4(pos, 1.0f));
+    f2 curr_ndc = mk2(curr_clip.x / curr_clip.w, curr_clip.y / curr_clip.w);
+    f2 prev_ndc = mk2(prev_clip.x / prev_clip.w, prev_clip.y / prev_clip.w);
+    f2 curr_uv = curr_ndc * mk2(0.5f, -0.5f) + mk2(0.5f, 0.5f);
+    f2 prev_uv = prev_ndc * mk2(0.5f, -0.5f) + mk2(0.5f, 0.5f);
+    f2 motion = prev_uv - curr_uv;
+    f2 en = encode_octahedral_normal(final_normal);
+    fv.gpos[pix] = make_float4(pos.x, pos.y, pos.z, (float)g.mat_id);
+    fv.gnormal[pix] = make_float4(en.x, en.y, g.uv.x, g.uv.y);
+    fv.galbedo[pix] = pack_rgba8(mk4(base_color, 1.0f));
+    fv.gmotion[pix] = make_float2(motion.x, motion.y);
+}
+
+// ================================================================================================ stage 1
+// restir.wgsl:788-918
+FRT_HD bool is_valid_neighbor_temporal(f3 cp, f3 cn, uint32_t cm, f3 pp, f3 pn, uint32_t pm, f3 cam) {   // :758-778
+    if (cm != pm) return false;
+    if (dot(cn, pn) < 0.99f) return false;
+    float dist_diff_sq = dot(cp - pp, cp - pp);
+    float dist_to_camera_sq = dot(cp - cam, cp - cam);
+    float threshold = fmaxn(0.00001f, dist_to_camera_sq * 0.001f);
+    return !(dist_diff_sq > threshold);
+}
+FRT_HD void temporal_pixel(PathCtx& c, uint32_t px, uint32_t py) {
+    const SceneView& sc = c.sc; const FrameView& fv = c.fv;
+    uint32_t pixel_idx = px + py * fv.W;
+    uint32_t seed_base = pixel_idx + fv.cam.frame_count * 927163u;
+    uint32_t seed_candidate = pcg_hash(seed_base);
+    uint32_t local_seed = seed_base;
+    float4 pos_w = fv.gpos[pixel_idx];
+    if (pos_w.w < 0.0f) { fv.res_temporal[pixel_idx] = zero_reservoir(); return; }
+    ReservoirView r = zero_reservoir();
+    PathOut path = trace_path<0>(c, pixel_idx, seed_candidate);
+    float p_hat = luminance(path.radiance);
+    update_reservoir(r, seed_candidate, p_hat, 0.5f, 1u, p_hat, path.v1_pos);
+    r.W = p_hat > 0.0f ? 1.0f : 0.0f;
+
+    float2 motion = fv.gmotion[pixel_idx];
+    f2 size = mk2((float)fv.W, (float)fv.H);
+    f2 uv = (mk2((float)px, (float)py) + mk2(0.5f, 0.5f)) / size;
+    f2 prev_uv = uv + mk2(motion.x, motion.y);
+    if (prev_uv.x >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y >= 0.0f && prev_uv.y <= 1.0f) {
+        f2 pf = prev_uv * size;
+        uint32_t qx = (uint32_t)pf.x, qy = (uint32_t)pf.y;
+        bool inb = qx < fv.W && qy < fv.H;          // prev_uv == 1.0: out-of-range texel reads give zeros
+        uint32_t prev_idx = inb ? qy * fv.W + qx : 0u;
+        float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4 prev_pos = inb ? fv.gpos_prev[prev_idx] : zero4;
+        float4 prev_nrm = inb ? fv.gnormal_prev[prev_idx] : zero4;
+        f3 prev_normal = decode_octahedral_normal(prev_nrm.x, prev_nrm.y);
+        uint32_t prev_mat_id = (uint32_t)(prev_pos.w + 0.1f);
+        float4 cur_nrm = fv.gnormal[pixel_idx];
+        f3 curr_normal = decode_octahedral_normal(cur_nrm.x, cur_nrm.y);
+        uint32_t curr_mat_id = (uint32_t)(pos_w.w + 0.1f);
+        const MaterialView& mat = sc.materials[curr_mat_id];
+        bool is_specular = mat.roughness < 0.2f || mat.metallic > 0.8f || (mat.transmission > 0.01f);
+        f3 cam = mk3(fv.cam.view_pos[0], fv.cam.view_pos[1], fv.cam.view_pos[2]);
+        if (is_valid_neighbor_temporal(mk3(pos_w.x, pos_w.y, pos_w.z), curr_normal, curr_mat_id,
+                                       mk3(prev_pos.x, prev_pos.y, prev_pos.z), prev_normal, prev_mat_id, cam) && !is_specular) {
+            ReservoirView prev_r = inb ? fv.res_spatial[prev_idx] : zero_reservoir();
+            f3 curr_albedo = xyz(unpack_rgba8(fv.galbedo[pixel_idx]));
+            f3 prev_albedo = inb ? xyz(unpack_rgba8(fv.galbedo_prev[prev_idx])) : splat3(0.0f);
+            float l_curr = luminance(curr_albedo) + 0.001f;
+            float l_prev = luminance(prev_albedo) + 0.001f;
+            float albedo_ratio = l_curr / l_prev;
+            if (albedo_ratio < 3.0f && albedo_ratio > 0.33f) {
+                float p_hat_new = prev_r.p_hat * albedo_ratio;
+                if (p_hat_new > 0.0f) {
+                    uint32_t clamped_M = prev_r.M < 16u ? prev_r.M : 16u;   // MAX_RESERVOIR_M_TEMPORAL, :851
+                    float w_prev = p_hat_new * prev_r.W * (float)clamped_M;
+                    update_reservoir(r, prev_r.y, w_prev, rand_lcg(local_seed), clamped_M, p_hat_new, mk3(prev_r.sx, prev_r.sy, prev_r.sz));
+                }
+            }
+        }
+    }
+    float p_hat_final = r.p_hat;
+    if (p_hat_final > 0.0f) r.W = (1.0f / p_hat_final) * (r.w_sum / (float)r.M);
+    else { r.W = 0.0f; r.p_hat = 0.0f; }
+    fv.res_temporal[pixel_idx] = r;
+}
+
+// ================================================================================================ stage 2
+// restir_spatial.wgsl:857-1016
+FRT_HD bool is_valid_neighbor_spatial(const SceneView& sc, f3 cp, f3 cn, uint32_t cm, f3 pp, f3 pn, uint32_t pm, f3 cam) {   // :783-814
+    if (cm != pm) return false;
+    const MaterialView& mat = sc.materials[cm];
+    bool is_specular = mat.roughness < 0.2f || mat.metallic > 0.8f || (mat.transmission > 0.01f);
+    if (is_specular) {
+        if (dot(cn, pn) < 0.998f) return false;
+        if (distance(cp, pp) > 0.01f) return false;
+    } else {
+        if (dot(cn, pn) < 0.995f) return false;
+        float dist_to_camera_sq = dot(cp - cam, cp - cam);
+        float threshold = fmaxn(0.00001f, dist_to_camera_sq * 0.001f);
+        float dist_diff_sq = dot(cp - pp, cp - pp);
+        if (dist_diff_sq > threshold) return false;
+    }
+    return true;
+}
+FRT_HD float calculate_jacobian(f3 curr_pos, f3 curr_normal, f3 curr_albedo, f3 n_v1, f3 n_pos, f3 n_normal, f3 n_albedo) {   // :822-854
+    float cos_curr = fmaxn(dot(curr_normal, normalize(n_v1 - curr_pos)), 0.0f);
+    float cos_neigh = fmaxn(dot(n_normal, normalize(n_v1 - n_pos)), 0.0f);
+    if (cos_neigh <= 0.001f) return 0.0f;
+    float jacobian = cos_curr / cos_neigh;
+    float lum_curr = luminance(curr_albedo) + 0.001f;
+    float lum_neigh = luminance(n_albedo) + 0.001f;
+    jacobian = jacobian * (lum_curr / lum_neigh);
+    return clampf(jacobian, 0.1f, 10.0f);
+}
+FRT_HD void spatial_pixel(PathCtx& c, uint32_t px, uint32_t py) {
+    const SceneView& sc = c.sc; const FrameView& fv = c.fv;
+    uint32_t pixel_idx = py * fv.W + px;
+    uint32_t seed_init = py * fv.W + px + fv.frame_count * 0x12345678u;   // scene_info.y (restir_spatial.rs execute)
+    uint32_t local_seed = seed_init;
+    float4 pos_w4 = fv.gpos[pixel_idx];
+    if (pos_w4.w < 0.0f) {
+        fv.res_spatial[pixel_idx] = zero_reservoir();
+        fv.raw[pixel_idx] = pack_rgba16f(mk4(0.0f, 0.0f, 0.0f, 0.0f));
+        return;
+    }
+    f3 pos_w = mk3(pos_w4.x, pos_w4.y, pos_w4.z);
+    float4 normal_w = fv.gnormal[pixel_idx];
+    f3 normal = decode_octahedral_normal(normal_w.x, normal_w.y);
+    uint32_t mat_id = (uint32_t)(pos_w4.w + 0.1f);
+    f3 albedo = xyz(unpack_rgba8(fv.galbedo[pixel_idx]));
+    ReservoirView r = fv.res_temporal[pixel_idx];
+    if (r.M > 20u) { r.w_sum *= 20.0f / (float)r.M; r.M = 20u; }
+    f3 camera_pos = mk3(fv.cam.view_pos[0], fv.cam.view_pos[1], fv.cam.view_pos[2]);
+    const MaterialView& mat = sc.materials[mat_id];
+    const bool narrow = mat.roughness < 0.1f || mat.metallic > 0.9f || mat.transmission > 0.1f;   // :906 and :957
+    uint32_t num_neighbors = narrow ? 3u : 5u;
+    float radius = narrow ? 4.0f : 10.0f;
+    for (uint32_t i = 0u; i < num_neighbors; i++) {
+        float r1 = rand_lcg(local_seed);
+        float r2 = rand_lcg(local_seed);
+        float angle = 2.0f * kPI * r1;
+        float rad = sqrtf_(r2) * radius;
+        float sa, ca;
+        sincosf_(angle, sa, ca);
+        f2 offset = mk2(ca, sa) * rad;
+        int nx = (int)px + (int)offset.x, ny = (int)py + (int)offset.y;   // vec2<i32>(offset) truncates toward zero
+        if (nx < 0 || nx >= (int)fv.W || ny < 0 || ny >= (int)fv.H) continue;
+        uint32_t nidx = (uint32_t)ny * fv.W + (uint32_t)nx;
+        float4 n_pos4 = fv.gpos[nidx];
+        if (n_pos4.w < 0.0f) continue;
+        f3 n_pos = mk3(n_pos4.x, n_pos4.y, n_pos4.z);
+        float4 n_nrm = fv.gnormal[nidx];
+        f3 n_normal = decode_octahedral_normal(n_nrm.x, n_nrm.y);
+        uint32_t n_mat_id = (uint32_t)(n_pos4.w + 0.1f);
+        f3 n_albedo = xyz(unpack_rgba8(fv.galbedo[nidx]));
+        if (!is_valid_neighbor_spatial(sc, pos_w, normal, mat_id, n_pos, n_normal, n_mat_id, camera_pos)) continue;
+        ReservoirView nr = fv.res_temporal[nidx];
+        if (nr.p_hat <= 0.0f) continue;
+        f3 n_s_path = mk3(nr.sx, nr.sy, nr.sz);
+        float jacobian = calculate_jacobian(pos_w, normal, albedo, n_s_path, n_pos, n_normal, n_albedo);
+        if (narrow) { if (jacobian < 0.5f || jacobian > 2.0f) continue; }
+        f3 dir_to_v1 = n_s_path - pos_w;
+        float dist_to_v1 = length(dir_to_v1);
+        bool visible = false;
+        if (dot(normal, dir_to_v1) > 0.0f) {
+            if (dist_to_v1 > 0.001f) {
+                f3 ray_dir = normalize(dir_to_v1);
+                float t_max = fmaxn(dist_to_v1, 0.0f);
+                if (trace_shadow_ray<1>(c, pos_w, ray_dir, t_max)) visible = true;
+            }
+        }
+        if (!visible) continue;
+        float p_hat_corrected = nr.p_hat * jacobian;
+        uint32_t M_new = nr.M < 20u ? nr.M : 20u;
+        float weight = p_hat_corrected * nr.W * (float)M_new;
+        update_reservoir(r, nr.y, weight, rand_lcg(local_seed), M_new, p_hat_corrected, n_s_path);
+    }
+    PathOut fin = trace_path<1>(c, pixel_idx, r.y);
+    f3 final_color = splat3(0.0f);
+    float p_hat_final = luminance(fin.radiance);
+    r.sx = fin.v1_pos.x; r.sy = fin.v1_pos.y; r.sz = fin.v1_pos.z;
+    if (p_hat_final > 0.0f) {
+        float w_unclamped = (1.0f / p_hat_final) * (r.w_sum / (float)r.M);
+        r.W = clampf(w_unclamped, 0.0f, 20.0f);
+        final_color = fin.radiance * r.W;
+        r.p_hat = p_hat_final;
+    } else { r.W = 0.0f; r.p_hat = 0.0f; }
+    fv.res_spatial[pixel_idx] = r;
+    fv.raw[pixel_idx] = pack_rgba16f(mk4(final_color, 1.0f));
+}
+
+// ================================================================================================ stage 3
+// post.wgsl:61-282. jitter == 0 (camera.rs:202-203): textureSampleLevel(raw_tex / albedo_tex) lands on texel centres -> texel fetch.
+FRT_HD float gauss(float x, float sigma) {   // post.wgsl:21-26 (sigma >= 0.001 at every call site)
+    return expf_(-(x * x) / (2.0f * sigma * sigma));
+}
+FRT_HD f3 rgb_to_ycocg(f3 c) {
+    return mk3(c.x * 0.25f + c.y * 0.5f + c.z * 0.25f, c.x * 0.5f + c.y * 0.0f + c.z * -0.5f, c.x * -0.25f + c.y * 0.5f + c.z * -0.25f);
+}
+FRT_HD f3 ycocg_to_rgb(f3 c) { return mk3(c.x + c.y - c.z, c.x + c.z, c.x - c.y - c.z); }
+FRT_HD f3 resolve_tonemap(f3 c) { return c / (1.0f + fmaxn(c.x, fmaxn(c.y, c.z))); }
+FRT_HD f3 resolve_inverse_tonemap(f3 c) { return c / (1.0f - fmaxn(c.x, fmaxn(c.y, c.z))); }
+
+FRT_HD void post_pixel(const FrameView& fv, uint32_t px, uint32_t py) {
+    int W = (int)fv.W, H = (int)fv.H;
+    uint32_t idx = py * fv.W + px;
+    f3 center_color = xyz(unpack_rgba16f(fv.raw[idx]));
+    f3 center_albedo = xyz(unpack_rgba8(fv.galbedo[idx]));
+    float4 cn = fv.gnormal[idx];
+    f3 center_normal = decode_octahedral_normal(cn.x, cn.y);
+    float4 cp4 = fv.gpos[idx];
+    f3 center_pos = mk3(cp4.x, cp4.y, cp4.z);
+    f3 sum_color = splat3(0.0f);
+    float sum_weight = 0.0f;
+    for (int dy = -2; dy <= 2; dy++) {
+        for (int dx = -2; dx <= 2; dx++) {
+            int nx = (int)px + dx, ny = (int)py + dy;
+            if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+            uint32_t nidx = (uint32_t)ny * fv.W + (uint32_t)nx;
+            f3 sample_color = xyz(unpack_rgba16f(fv.raw[nidx]));
+            f3 sample_albedo = xyz(unpack_rgba8(fv.galbedo[nidx]));
+            float4 sn = fv.gnormal[nidx];
+            f3 sample_normal = decode_octahedral_normal(sn.x, sn.y);
+            float4 sp4 = fv.gpos[nidx];
+            f3 sample_pos = mk3(sp4.x, sp4.y, sp4.z);
+            float w_spatial = gauss(length2(mk2((float)dx, (float)dy)), 1.5f);
+            float w_color = gauss(length(sample_albedo - center_albedo), 0.2f);
+            float dot_normal = clampf(dot(center_normal, sample_normal), 0.0f, 1.0f);
+            float w_normal = powf_(dot_normal, 20.0f);
+            float w_pos = gauss(length(sample_pos - center_pos), 0.1f);
+            float weight = w_spatial * w_color * w_normal * w_pos;
+            sum_color = sum_color + sample_color * weight;
+            sum_weight += weight;
+        }
+    }
+    f3 filtered_color = center_color;
+    if (sum_weight > 0.001f) filtered_color = sum_color / sum_weight;
+    f3 m1 = splat3(0.0f), m2 = splat3(0.0f);
+    f3 tm_filtered = resolve_tonemap(filtered_color);
+    for (int dy = -1; dy <= 1; dy++) {
+        for (int dx = -1; dx <= 1; dx++) {
+            int nx = (int)px + dx, ny = (int)py + dy;
+            f3 s_col = filtered_color;
+            if (nx >= 0 && ny >= 0 && nx < W && ny < H) s_col = xyz(unpack_rgba16f(fv.raw[(uint32_t)ny * fv.W + (uint32_t)nx]));
+            f3 s_ycocg = rgb_to_ycocg(resolve_tonemap(s_col));
+            m1 = m1 + s_ycocg;
+            m2 = m2 + s_ycocg * s_ycocg;
+        }
+    }
+    m1 = m1 / 9.0f; m2 = m2 / 9.0f;
+    f3 var = max3(splat3(0.0f), m2 - m1 * m1);
+    f3 sigma = mk3(sqrtf_(var.x), sqrtf_(var.y), sqrtf_(var.z));
+    f3 c_min = m1 - sigma * 1.2f;
+    f3 c_max = m1 + sigma * 1.2f;
+    f3 history_color = tm_filtered;
+    bool valid_history = false;
+    f2 structure_motion = mk2(0.0f, 0.0f);
+    if (fv.frame_count > 0u) {
+        float2 mv = fv.gmotion[idx];
+        structure_motion = mk2(mv.x, mv.y);
+        f2 size = mk2((float)fv.W, (float)fv.H);
+        f2 uv = (mk2((float)px, (float)py) + mk2(0.5f, 0.5f)) / size;
+        f2 prev_uv = uv + structure_motion;
+        f2 prev_pos = prev_uv * size - mk2(0.5f, 0.5f);
+        float fpx = floorf_(prev_pos.x), fpy = floorf_(prev_pos.y);
+        int p0x = (int)fpx, p0y = (int)fpy;
+        float fx = prev_pos.x - fpx, fy = prev_pos.y - fpy;
+        if (prev_uv.x >= 0.0f && prev_uv.y >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y <= 1.0f) {
+            f3 c4[4];
+            for (int k = 0; k < 4; ++k) {
+                int x = p0x + (k & 1), y = p0y + (k >> 1);
+                c4[k] = splat3(0.0f);
+                if (x >= 0 && y >= 0 && x < W && y < H) {
+                    float4 hv = fv.history[(uint32_t)y * fv.W + (uint32_t)x];
+                    c4[k] = resolve_tonemap(mk3(hv.x, hv.y, hv.z));
+                }
+            }
+            f3 c01 = mix3(c4[0], c4[1], fx);
+            f3 c23 = mix3(c4[2], c4[3], fx);
+            history_color = mix3(c01, c23, fy);
+            valid_history = true;
+        }
+    }
+    f3 final_tm = tm_filtered;
+    if (valid_history) {
+        f3 clamped_history = ycocg_to_rgb(clamp3(rgb_to_ycocg(history_color), c_min, c_max));
+        f2 motion_px = structure_motion * mk2((float)fv.W, (float)fv.H);
+        float speed = length2(motion_px);
+        if (speed < 0.5f) {
+            float accum_blend = 1.0f - (1.0f / (float)(fv.frame_count + 1u));
+            final_tm = mix3(tm_filtered, history_color, clampf(accum_blend, 0.0f, 1.0f));
+        } else {
+            float dynamic_feedback = mixf(0.98f, 0.85f, smoothstepf(0.0f, 2.0f, speed));
+            final_tm = mix3(tm_filtered, clamped_history, dynamic_feedback);
+        }
+    }
+    f3 final_color = max3(splat3(0.0f), resolve_inverse_tonemap(final_tm));
+    fv.accum[idx] = make_float4(final_color.x, final_color.y, final_color.z, 1.0f);
+    const float inv_gamma = (float)(1.0 / 2.2);
+    fv.display[idx] = pack_rgba8(mk4(powf_(final_color.x, inv_gamma), powf_(final_color.y, inv_gamma), powf_(final_color.z, inv_gamma), 1.0f));
+}
+
+} // namespace frt

@@ -1,0 +1,144 @@
+// frt_trace.hpp — software ray traversal: replaces rayQueryInitialize / rayQueryProceed /
+// rayQueryGetCommittedIntersection (gbuffer.wgsl:108-112, restir.wgsl:376-380, :601-607,
+// restir_spatial.wgsl:397-399, :627-633), i.e. the Vulkan driver's BVH walk and ray/triangle test.
+//
+// Hit semantics (they do not depend on the tree):
+//   triangle hit  <=>  det != 0, 0 <= u <= 1, v >= 0, u + v <= 1, tmin < t < tmax   (Möller–Trumbore, f32, no FMA)
+//   closest hit    =   min t, ties -> smallest flattened triangle id
+//   any hit        =   exists a triangle hit (RayDesc flag 0x4)
+//   front face    <=>  det > 0 (xor instance flip)
+// Box tests may use fmaf: they only prune, and boxes are padded on the host (frt_bvh.cpp).
+#pragma once
+#include "frt_math.hpp"
+
+namespace frt {
+
+static const int kStackDepth = 32;
+
+struct InstanceView { uint32_t mesh_id, mat_id, first_tri, flip; float w2o[9]; float pad[3]; };   // = InstanceDev (64 B)
+struct MeshInfoView { uint32_t vertex_offset, index_offset, pad0, pad1; };
+struct VertexAttrView { float normal[2]; float uv[2]; float tangent[4]; };
+struct MaterialView {
+    float base_color[4]; float emissive_factor[3]; float roughness; float metallic, transmission, ior; int32_t light_index;
+    uint32_t tex_info_0, tex_info_1, tex_info_2, pad_final;
+};
+struct LightView { float position[3]; uint32_t type_; float u[3]; float area; float v[3]; uint32_t pad; float emission[4]; };
+
+// Read-only scene replica resident in HBM (one per GPU). All arrays are 16-byte aligned.
+struct SceneView {
+    const float4* nodes;        // pair nodes, 4 x float4 each
+    const float4* tris;         // triangle slots, 3 x float4 each
+    const InstanceView* instances;
+    const MeshInfoView* mesh_infos;
+    const VertexAttrView* attributes;
+    const uint32_t* indices;
+    const MaterialView* materials;
+    const LightView* lights;
+    const uint8_t* color_tex;   // layers of 1024*1024*4 bytes (sRGB8)
+    const uint8_t* data_tex;    // layers of 1024*1024*4 bytes (unorm8)
+    const float* srgb_lut;      // 256 floats
+    uint32_t num_materials, num_lights, num_nodes, num_tris;
+};
+
+struct HitRec {
+    float t, u, v;
+    uint32_t tri;      // flattened triangle id, 0xFFFFFFFF = miss
+    uint32_t inst;
+    bool front;
+};
+
+struct RayCounters { uint32_t closest, any; };
+
+// Möller–Trumbore, contract arithmetic (identical operation order in the CPU checker).
+FRT_HD bool intersect_tri(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float tmin, float tmax, float& t, float& u, float& v, float& det_out) {
+    f3 p = cross(d, e2);
+    float det = dot(e1, p);
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    f3 s = o - v0;
+    float uu = dot(s, p) * inv;
+    if (!(uu >= 0.0f && uu <= 1.0f)) return false;
+    f3 q = cross(s, e1);
+    float vv = dot(d, q) * inv;
+    if (!(vv >= 0.0f && uu + vv <= 1.0f)) return false;
+    float tt = dot(e2, q) * inv;
+    if (!(tt > tmin && tt < tmax)) return false;
+    t = tt; u = uu; v = vv; det_out = det;
+    return true;
+}
+
+// Slab test of one child box against the ray interval [tmin, tlim]. Not contract code (fmaf allowed).
+FRT_HD bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 inv, f3 oinv, float tmin, float tlim, float& tnear) {
+    float x0 = __builtin_fmaf(lox, inv.x, oinv.x), x1 = __builtin_fmaf(hix, inv.x, oinv.x);
+    float y0 = __builtin_fmaf(loy, inv.y, oinv.y), y1 = __builtin_fmaf(hiy, inv.y, oinv.y);
+    float z0 = __builtin_fmaf(loz, inv.z, oinv.z), z1 = __builtin_fmaf(hiz, inv.z, oinv.z);
+    float tn = fmaxn(fmaxn(fminn(x0, x1), fminn(y0, y1)), fmaxn(fminn(z0, z1), tmin));
+    float tf = fminn(fminn(fmaxn(x0, x1), fmaxn(y0, y1)), fminn(fmaxn(z0, z1), tlim));
+    tnear = tn;
+    return tn <= tf * 1.0000004f;
+}
+
+// ANY = true: terminate on the first accepted hit (shadow / visibility rays); returns hit.tri != miss.
+// `stk` is this lane's traversal stack: kStackDepth entries, `stride` words apart (LDS column on the device).
+template <bool ANY>
+FRT_HD void trace(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint32_t* stk, uint32_t stride, HitRec& hit) {
+    hit.t = tmax; hit.tri = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f; hit.inst = 0u; hit.front = false;
+    float best_det = 0.0f;
+    // 1/d with |d| clamped to 2^-80: keeps inv finite so that fma(b, inv, -o*inv) never evaluates inf - inf (a ray lying
+    // in an axis plane, d.y == 0, is common here: reconnection rays along a wall). Pruning only; not contract arithmetic.
+    const float kTiny = 8.271806125530277e-25f;
+    f3 inv = mk3(1.0f / (fabsf_(d.x) > kTiny ? d.x : __builtin_copysignf(kTiny, d.x)),
+                 1.0f / (fabsf_(d.y) > kTiny ? d.y : __builtin_copysignf(kTiny, d.y)),
+                 1.0f / (fabsf_(d.z) > kTiny ? d.z : __builtin_copysignf(kTiny, d.z)));
+    f3 oinv = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    int sp = 0;
+    uint32_t cur = 0u;   // pair node 0 is the root
+    for (;;) {
+        if (!(cur & 0x80000000u)) {
+            const float4* n = sc.nodes + (size_t)cur * 4u;
+            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            float tlim = ANY ? tmax : hit.t;
+            float t0, t1;
+            bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, inv, oinv, tmin, tlim, t0);
+            bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, inv, oinv, tmin, tlim, t1);
+            uint32_t r0 = f2u(q3.x), r1 = f2u(q3.y);
+            h0 = h0 && (r0 != 0xFFFFFFFFu);   // absent child (single-leaf scenes)
+            h1 = h1 && (r1 != 0xFFFFFFFFu);
+            if (h0 && h1) {
+                bool swap = t1 < t0;
+                uint32_t nearr = swap ? r1 : r0, farr = swap ? r0 : r1;
+                stk[(uint32_t)sp * stride] = farr; ++sp;
+                cur = nearr;
+            } else if (h0) cur = r0;
+            else if (h1) cur = r1;
+            else {
+                if (sp == 0) break;
+                --sp; cur = stk[(uint32_t)sp * stride];
+            }
+            continue;
+        }
+        // leaf
+        uint32_t first = cur & 0x00FFFFFFu, count = (cur >> 24) & 0x7Fu;
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4* tp = sc.tris + (size_t)(first + k) * 3u;
+            float4 a = tp[0], b = tp[1], c = tp[2];
+            float t, u, v, det;
+            if (intersect_tri(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, d, tmin, tmax, t, u, v, det)) {
+                uint32_t id = f2u(a.w);
+                if (ANY) { hit.tri = id; hit.t = t; return; }
+                if (t < hit.t || (t == hit.t && id < hit.tri)) {
+                    hit.t = t; hit.u = u; hit.v = v; hit.tri = id; hit.inst = f2u(b.w); best_det = det;
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = stk[(uint32_t)sp * stride];
+    }
+    if (!ANY && hit.tri != 0xFFFFFFFFu) {
+        bool front = best_det > 0.0f;
+        if (sc.instances[hit.inst].flip) front = !front;
+        hit.front = front;
+    }
+}
+
+} // namespace frt

@@ -1,0 +1,86 @@
+"""Renderer mirror (src/renderer.rs) over frt_renderer_*. Every pixel is produced by the HIP kernels in libfrt.so."""
+import ctypes as C
+import numpy as np
+from ._lib import (lib, check, FrtError, RenderOpts, Stats, CameraUniform, BUF_BPP, BUF_ACCUM, BUF_DISPLAY, PHASE_ALL)
+
+
+class Renderer:
+    def __init__(self, scene, width, height, max_depth=8, device=0, stream=None, rows=None, arena=None, arena_bytes=0, flags=0):
+        """Renderer::new (renderer.rs:206). rows=(begin,end) restricts this renderer to an image strip."""
+        o = RenderOpts()
+        o.max_depth, o.device, o.flags = max_depth, device, flags
+        o.stream = stream
+        if rows is not None:
+            o.row_begin, o.row_end = rows
+        if arena is not None:
+            o.device_arena, o.arena_bytes = arena, arena_bytes
+        self.width, self.height = width, height
+        self._scene = scene     # keep the scene alive
+        self._h = lib().frt_renderer_create(scene._h, width, height, C.byref(o))
+        if not self._h:
+            raise FrtError("renderer creation failed: " + lib().frt_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().frt_renderer_destroy(self._h)
+            self._h = None
+
+    @staticmethod
+    def arena_bytes(width, height):
+        return int(lib().frt_renderer_arena_bytes(width, height))
+
+    def aspect_ratio(self):      # renderer.rs:202
+        return self.width / self.height
+
+    @property
+    def frame_count(self):       # renderer.rs:198
+        return int(lib().frt_renderer_frame_count(self._h))
+
+    def render(self, camera_uniform):      # renderer.rs:349
+        check(lib().frt_renderer_render(self._h, C.byref(camera_uniform)))
+
+    def render_phases(self, camera_uniform, phases=PHASE_ALL):
+        check(lib().frt_renderer_render_phases(self._h, C.byref(camera_uniform), phases))
+
+    def end_frame(self):
+        check(lib().frt_renderer_end_frame(self._h))
+
+    def sync(self):
+        check(lib().frt_renderer_sync(self._h))
+
+    def reset(self):             # state.rs:152 / renderer.rs:346
+        check(lib().frt_renderer_reset(self._h))
+
+    def clear(self):
+        check(lib().frt_renderer_clear(self._h))
+
+    def read_buffer(self, buf, index=0):
+        bpp = BUF_BPP[buf]
+        out = np.zeros((self.height, self.width, bpp), np.uint8)
+        check(lib().frt_renderer_read_buffer(self._h, buf, index, out.ctypes.data))
+        return out
+
+    def read_display(self):
+        return self.read_buffer(BUF_DISPLAY)
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        check(lib().frt_renderer_read_accum(self._h, out.ctypes.data))
+        return out
+
+    def buffer_info(self, buf, index=0):
+        p, bpp = C.c_void_p(), C.c_uint32()
+        check(lib().frt_renderer_buffer_info(self._h, buf, index, C.byref(p), C.byref(bpp)))
+        return p.value, bpp.value
+
+    def phase_rows(self):
+        r = (C.c_uint32 * 8)()
+        check(lib().frt_renderer_phase_rows(self._h, r))
+        v = list(r)
+        return {"gbuffer": (v[0], v[1]), "temporal": (v[2], v[3]), "spatial": (v[4], v[5]), "post": (v[6], v[7])}
+
+    def stats(self):
+        s = Stats()
+        check(lib().frt_renderer_stats(self._h, C.byref(s)))
+        return {"rays_closest": s.rays_closest, "rays_any": s.rays_any, "frames": s.frames,
+                "ms_stage": list(s.ms_stage), "launches": list(s.launches)}

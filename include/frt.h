@@ -1,0 +1,183 @@
+/* frt.h — C ABI of the MI355X-native path tracer (drop-in boundary for the hot path of
+ * kokutoupan/fast-raytracing-wgpu: G-buffer -> ReSTIR-PT temporal -> ReSTIR-PT spatial + shade -> post/accumulate).
+ *
+ * The reference has no FFI; the seam is the Rust API between `State` and `SceneBuilder` / `Renderer`
+ * (src/state.rs:57-80, :192-204). Every entry point below names the reference interface it replaces.
+ * All structs are byte-identical to the reference's #[repr(C)] types. Plain pointers and sizes only.
+ *
+ * Conventions: functions returning int return 0 (FRT_OK) or a negative frt_status; the message for the last
+ * failure on the calling thread is frt_last_error(). Handles are not thread-safe (like the reference, which
+ * drives everything from the winit main thread). Inputs are copied; outputs go to caller-owned buffers.
+ * There is NO CPU rendering path: every render entry point fails with FRT_ERR_NO_DEVICE without a HIP device.
+ */
+#ifndef FRT_H
+#define FRT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum frt_status {
+    FRT_OK = 0,
+    FRT_ERR_INVALID_ARG = -1,
+    FRT_ERR_NO_DEVICE = -2,    /* no HIP device / HIP runtime error: the product never falls back to the CPU */
+    FRT_ERR_HIP = -3,
+    FRT_ERR_STATE = -4,        /* call order (e.g. render before build) */
+    FRT_ERR_LIMIT = -5         /* scene exceeds a compiled limit (BVH depth vs traversal stack, u16 ids) */
+} frt_status;
+
+/* ---- data types ------------------------------------------------------------------------- */
+
+/* src/geometry.rs:4-10 — VertexAttributes, 32 B */
+typedef struct frt_vertex_attr { float normal[2]; float uv[2]; float tangent[4]; } frt_vertex_attr;
+
+/* src/scene/material.rs:2-28 — Material, 64 B. Texture ids are u16 pairs, 0xFFFF = none. */
+typedef struct frt_material {
+    float base_color[4];
+    float emissive_factor[3];
+    float roughness;
+    float metallic, transmission, ior;
+    int32_t light_index;
+    uint32_t tex_info_0;   /* [base colour tex (low), normal tex (high)] */
+    uint32_t tex_info_1;   /* [occlusion tex (low), emissive tex (high)] */
+    uint32_t tex_info_2;   /* [metallic-roughness tex (low), pad] */
+    uint32_t pad_final;
+} frt_material;
+
+/* src/scene/light.rs:1-16 — LightUniform, 64 B. type_: 0 quad, 1 sphere (v[0] = radius). */
+typedef struct frt_light {
+    float position[3]; uint32_t type_;
+    float u[3]; float area;
+    float v[3]; uint32_t pad;
+    float emission[4];
+} frt_light;
+
+/* src/camera.rs:4-15 — CameraUniform, 288 B, matrices column-major. */
+typedef struct frt_camera_uniform {
+    float view_proj[16];
+    float view_inverse[16];
+    float proj_inverse[16];
+    float view_pos[4];
+    float prev_view_proj[16];
+    uint32_t frame_count, num_lights, padding[2];
+} frt_camera_uniform;
+
+/* src/passes/restir.rs:5-14 — Reservoir, 32 B */
+typedef struct frt_reservoir { uint32_t y; float w_sum; uint32_t M; float W; float s_path[3]; float p_hat; } frt_reservoir;
+
+/* Canonical BVH2 node, 32 B (replaces the opaque driver BLAS/TLAS of src/scene/builder.rs:143-179, :454-468).
+ * count > 0: leaf over tri_index[left_first .. left_first + count); count == 0: children left_first, left_first + 1. */
+typedef struct frt_bvh2_node { float bmin[3]; uint32_t left_first; float bmax[3]; uint32_t count; } frt_bvh2_node;
+
+typedef struct frt_scene frt_scene;
+typedef struct frt_renderer frt_renderer;
+
+/* ---- errors --------------------------------------------------------------------------------------------- */
+const char* frt_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unavailable). Does not initialise a device context. */
+int frt_device_count(void);
+
+/* ---- geometry generators: src/geometry.rs:79-434 (create_*_blas without the wgpu BLAS handle) --------------
+ * which: 0 plane (:79), 1 cube (:120), 2 icosphere(subdiv) (:222), 3 crystal (:350).
+ * Call with null buffers to get counts; then with buffers of nverts*16, nverts*32, nidx*4 bytes. */
+int frt_geometry_create(int which, uint32_t subdiv, uint32_t* nverts, uint32_t* nidx,
+                        float* pos4, frt_vertex_attr* attrs, uint32_t* idx);
+/* src/geometry.rs:56-76 */
+void frt_encode_octahedral_normal(const float n[3], float out[2]);
+/* src/scene/material.rs:31-47 — Material::new defaults */
+void frt_material_default(const float base_color[4], frt_material* out);
+
+/* ---- scene: src/scene/builder.rs SceneBuilder --------------------------------------------------------------- */
+frt_scene* frt_scene_create(void);                                   /* SceneBuilder::new, :24 (default textures :41-91) */
+void frt_scene_destroy(frt_scene* s);
+int frt_scene_add_mesh(frt_scene* s, const float* pos4, uint32_t nverts, const frt_vertex_attr* attrs,
+                       const uint32_t* idx, uint32_t nidx);          /* add_mesh, :123 -> mesh id */
+int frt_scene_add_material(frt_scene* s, const frt_material* m);     /* add_material, :117 -> material id */
+int frt_scene_add_instance(frt_scene* s, uint32_t mesh_id, uint32_t mat_id, const float m_colmajor[16]);   /* add_instance, :181 (mask ignored there too) */
+int frt_scene_add_light(frt_scene* s, const frt_light* l);           /* lights.push, :406 / :420 -> light index */
+int frt_scene_register_quad_light(frt_scene* s, uint32_t mesh_id, const float m_colmajor[16], const float color[3], float intensity);   /* :316 */
+int frt_scene_register_sphere_light(frt_scene* s, uint32_t mesh_id, const float m_colmajor[16], const float color[3], float intensity); /* :353 */
+int frt_scene_add_texture(frt_scene* s, int kind /*0 colour (sRGB), 1 data*/, const uint8_t* rgba8_1024x1024);   /* :93-115 -> layer id */
+/* SceneBuilder::build, :431 — flattens instances, builds the SAH BVH on the host. No device work. */
+int frt_scene_build(frt_scene* s);
+/* src/scene/scenes.rs:9-130 and :133-223 — whole-scene factories (built). */
+frt_scene* frt_scene_create_cornell_box(void);
+frt_scene* frt_scene_create_restir_scene(void);
+
+/* Introspection (tests): counts[8] = tris, instances, materials, lights, meshes, attributes, indices, bvh2 nodes */
+int frt_scene_counts(const frt_scene* s, uint32_t counts[8]);
+/* which: 0 tris (9 f32: v0,e1,e2), 1 tri_instance (u32), 2 materials, 3 lights, 4 attributes, 5 indices, 6 mesh infos (16 B),
+ * 7 instances (120 B: mesh,mat,first_tri,tri_count,flip u32; m[16]; w2o[9] f32), 8 bvh2 nodes (32 B), 9 bvh2 tri_index (u32) */
+int frt_scene_get(const frt_scene* s, int which, void* out);
+/* bvh stats[4]: max depth, leaves, max leaf size, wide-node count */
+int frt_scene_bvh_stats(const frt_scene* s, uint32_t stats[4]);
+
+/* ---- camera: src/camera.rs:207-256 build_uniform at the initial pose (:40-42), jitter 0 (:202-203) ------------ */
+void frt_camera_default(float aspect, uint32_t frame_count, uint32_t num_lights, frt_camera_uniform* out);
+
+/* ---- renderer: src/renderer.rs ---------------------------------------------------------------------------- */
+typedef struct frt_render_opts {
+    uint32_t max_depth;       /* MAX_DEPTH, restir.wgsl:5; 0 -> 8 */
+    int32_t device;           /* HIP device ordinal */
+    void* stream;             /* hipStream_t to enqueue on; NULL -> a stream owned by the renderer */
+    uint32_t row_begin;       /* rows [row_begin, row_end) owned by this renderer (image strip); 0,0 -> whole image */
+    uint32_t row_end;
+    void* device_arena;       /* optional caller-owned device memory for all per-pixel buffers (frt_renderer_arena_bytes) */
+    uint64_t arena_bytes;
+    uint32_t flags;           /* FRT_FLAG_* */
+    uint32_t reserved;
+} frt_render_opts;
+#define FRT_FLAG_TIMING 1u    /* record per-stage HIP events every frame (frt_stats.ms_*) */
+
+enum { FRT_PHASE_GBUFFER = 1, FRT_PHASE_TEMPORAL = 2, FRT_PHASE_SPATIAL = 4, FRT_PHASE_POST = 8, FRT_PHASE_ALL = 15 };
+
+/* Per-pixel buffers (RenderTargets, src/renderer.rs:26-170; reservoirs src/passes/restir.rs:329-348) */
+enum {
+    FRT_BUF_GPOS = 0,        /* rgba32f  16 B/px, x2 ping-pong */
+    FRT_BUF_GNORMAL = 1,     /* rgba32f  16 B/px, x2 */
+    FRT_BUF_GALBEDO = 2,     /* rgba8    4 B/px, x2 */
+    FRT_BUF_GMOTION = 3,     /* rg32f    8 B/px */
+    FRT_BUF_RESERVOIR = 4,   /* 32 B/px, [0] temporal result, [1] spatial result */
+    FRT_BUF_RAW = 5,         /* rgba16f  8 B/px */
+    FRT_BUF_DISPLAY = 6,     /* rgba8    4 B/px */
+    FRT_BUF_ACCUM = 7        /* vec4f    16 B/px, x2 */
+};
+
+typedef struct frt_stats {
+    uint64_t rays_closest;    /* closest-hit rays issued (device-counted), since create/reset */
+    uint64_t rays_any;        /* any-hit (shadow / visibility) rays issued */
+    uint64_t frames;          /* frames rendered since create/reset */
+    double ms_stage[4];       /* summed kernel time per stage (gbuffer, temporal, spatial, post); FRT_FLAG_TIMING only */
+    uint64_t launches[4];     /* launches per stage */
+} frt_stats;
+
+uint64_t frt_renderer_arena_bytes(uint32_t width, uint32_t height);
+/* Renderer::new, src/renderer.rs:206. Uploads the scene replica to opts->device. */
+frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t height, const frt_render_opts* opts);
+void frt_renderer_destroy(frt_renderer* r);
+/* Renderer::render, src/renderer.rs:349 — enqueue the four stages for one frame, then frame_count += 1 (:515). Asynchronous. */
+int frt_renderer_render(frt_renderer* r, const frt_camera_uniform* cam);
+/* Strip form: enqueue only `phases` (multi-GPU: a halo exchange sits between TEMPORAL and SPATIAL); frt_renderer_end_frame advances frame_count. */
+int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, int phases);
+int frt_renderer_end_frame(frt_renderer* r);
+int frt_renderer_sync(frt_renderer* r);                       /* block until enqueued work is done */
+uint32_t frt_renderer_frame_count(const frt_renderer* r);     /* renderer.frame_count, :198 */
+int frt_renderer_reset(frt_renderer* r);                      /* frame_count = 0 only, as state.rs:152 / renderer.rs:346 (buffers keep their contents) */
+int frt_renderer_clear(frt_renderer* r);                      /* back to the state right after create: zeroed targets, frame_count = 0, stats = 0 */
+/* Read-back of post_processed_texture (state.rs:226-278) and of any other target; syncs first. index = ping-pong slot. */
+int frt_renderer_read_display(frt_renderer* r, uint8_t* rgba8);
+int frt_renderer_read_accum(frt_renderer* r, float* rgba32f);  /* the slot written by the last frame */
+int frt_renderer_read_buffer(frt_renderer* r, int buf, int index, void* out);
+/* Device address / geometry of a target, for halo exchange and gathers by the caller (rows are contiguous, full-frame pitch). */
+int frt_renderer_buffer_info(const frt_renderer* r, int buf, int index, void** device_ptr, uint32_t* bytes_per_pixel);
+/* Rows this renderer computes per phase given its strip: out[0..1] gbuffer, [2..3] temporal, [4..5] spatial, [6..7] post */
+int frt_renderer_phase_rows(const frt_renderer* r, uint32_t out[8]);
+int frt_renderer_stats(frt_renderer* r, frt_stats* out);      /* syncs first */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRT_H */

@@ -81,7 +81,8 @@ inline vec3 cross(vec3 a, vec3 b) {
 }
 inline float length(vec3 v) { return sqrtf(dot(v, v)); }
 inline float length2(vec2 v) { return sqrtf(dot2(v, v)); }
-inline vec3 normalize(vec3 v) { return v / length(v); }
+// normalize: v * (1 / length(v)) — one IEEE division, then three multiplies (contract; WGSL leaves it open)
+inline vec3 normalize(vec3 v) { float r = 1.0f / length(v); return v * r; }
 inline float distance(vec3 a, vec3 b) { return length(a - b); }
 inline vec3 reflect(vec3 i, vec3 n) { return i - n * (2.0f * dot(n, i)); }
 inline vec3 refract(vec3 i, vec3 n, float eta) {
