@@ -425,6 +425,24 @@ int frt_renderer_read_buffer(frt_renderer* r, int buf, int index, void* out) {
     HIP_TRY(hipMemcpy(out, r->buf(b), (size_t)r->W * r->H * kBpp[b], hipMemcpyDeviceToHost));
     return FRT_OK;
 }
+int frt_renderer_read_rows(frt_renderer* r, int buf, int index, uint32_t y0, uint32_t y1, void* out) {
+    int b = r ? buf_index(buf, index) : -1;
+    if (b < 0 || !out || y0 > y1 || y1 > r->H) return fail(FRT_ERR_INVALID_ARG, "read_rows: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    size_t pitch = (size_t)r->W * kBpp[b];
+    HIP_TRY(hipMemcpy(out, (uint8_t*)r->buf(b) + pitch * y0, pitch * (y1 - y0), hipMemcpyDeviceToHost));
+    return FRT_OK;
+}
+int frt_renderer_write_rows(frt_renderer* r, int buf, int index, uint32_t y0, uint32_t y1, const void* in) {
+    int b = r ? buf_index(buf, index) : -1;
+    if (b < 0 || !in || y0 > y1 || y1 > r->H) return fail(FRT_ERR_INVALID_ARG, "write_rows: bad arguments");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    size_t pitch = (size_t)r->W * kBpp[b];
+    HIP_TRY(hipMemcpy((uint8_t*)r->buf(b) + pitch * y0, in, pitch * (y1 - y0), hipMemcpyHostToDevice));
+    return FRT_OK;
+}
 int frt_renderer_read_display(frt_renderer* r, uint8_t* rgba8) { return frt_renderer_read_buffer(r, FRT_BUF_DISPLAY, 0, rgba8); }
 int frt_renderer_read_accum(frt_renderer* r, float* rgba32f) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "read_accum: null");

@@ -87,6 +87,8 @@ SYMBOLS = {
     "frt_renderer_read_display": (C.c_int, [_P, _P]),
     "frt_renderer_read_accum": (C.c_int, [_P, _P]),
     "frt_renderer_read_buffer": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "frt_renderer_read_rows": (C.c_int, [_P, C.c_int, C.c_int, _U32, _U32, _P]),
+    "frt_renderer_write_rows": (C.c_int, [_P, C.c_int, C.c_int, _U32, _U32, _P]),
     "frt_renderer_buffer_info": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_U32)]),
     "frt_renderer_phase_rows": (C.c_int, [_P, _P]),
     "frt_renderer_stats": (C.c_int, [_P, C.POINTER(Stats)]),

@@ -60,6 +60,16 @@ class Renderer:
         check(lib().frt_renderer_read_buffer(self._h, buf, index, out.ctypes.data))
         return out
 
+    def read_rows(self, buf, index, y0, y1):
+        out = np.zeros((y1 - y0, self.width, BUF_BPP[buf]), np.uint8)
+        check(lib().frt_renderer_read_rows(self._h, buf, index, y0, y1, out.ctypes.data))
+        return out
+
+    def write_rows(self, buf, index, y0, y1, data):
+        data = np.ascontiguousarray(data, np.uint8)
+        assert data.size == (y1 - y0) * self.width * BUF_BPP[buf]
+        check(lib().frt_renderer_write_rows(self._h, buf, index, y0, y1, data.ctypes.data))
+
     def read_display(self):
         return self.read_buffer(BUF_DISPLAY)
 

@@ -171,6 +171,9 @@ int frt_renderer_clear(frt_renderer* r);                      /* back to the sta
 int frt_renderer_read_display(frt_renderer* r, uint8_t* rgba8);
 int frt_renderer_read_accum(frt_renderer* r, float* rgba32f);  /* the slot written by the last frame */
 int frt_renderer_read_buffer(frt_renderer* r, int buf, int index, void* out);
+/* Row-range copies to / from the host: rows [y0, y1) of a target, tightly packed (gathers of image strips, halo exchange through the host). */
+int frt_renderer_read_rows(frt_renderer* r, int buf, int index, uint32_t y0, uint32_t y1, void* out);
+int frt_renderer_write_rows(frt_renderer* r, int buf, int index, uint32_t y0, uint32_t y1, const void* in);
 /* Device address / geometry of a target, for halo exchange and gathers by the caller (rows are contiguous, full-frame pitch). */
 int frt_renderer_buffer_info(const frt_renderer* r, int buf, int index, void** device_ptr, uint32_t* bytes_per_pixel);
 /* Rows this renderer computes per phase given its strip: out[0..1] gbuffer, [2..3] temporal, [4..5] spatial, [6..7] post */

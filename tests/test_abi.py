@@ -1,0 +1,81 @@
+"""The C-ABI library loads, exports every symbol include/frt.h declares, and fails loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "frt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(frt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(frt):
+    names = _declared_symbols()
+    assert len(names) >= 35
+    L = C.CDLL(os.path.join(ROOT, "fast-raytracing-wgpu_amd", "lib", "libfrt.so"))
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/frt.h but not exported"
+    # and the binding table used by the host mirror covers the same set
+    from frt._lib import SYMBOLS
+    assert sorted(SYMBOLS) == names
+
+
+def test_struct_layouts(frt):
+    assert C.sizeof(frt.VertexAttr) == 32 and C.sizeof(frt.Material) == 64 and C.sizeof(frt.Light) == 64
+    assert C.sizeof(frt.CameraUniform) == 288
+    assert frt.CameraUniform.view_pos.offset == 192 and frt.CameraUniform.prev_view_proj.offset == 208   # camera.rs:4-15 field order
+    assert frt.CameraUniform.frame_count.offset == 272
+    assert frt.Material.light_index.offset == 44 and frt.Material.tex_info_0.offset == 48
+
+
+def test_material_default(frt):
+    m = frt.material_new([0.1, 0.2, 0.3, 1.0])        # material.rs:31-47
+    assert list(m.base_color) == [np.float32(0.1), np.float32(0.2), np.float32(0.3), 1.0]
+    assert m.roughness == 0.5 and m.metallic == 0.0 and m.ior == 1.0 and m.light_index == -1
+    assert m.tex_info_0 == m.tex_info_1 == m.tex_info_2 == 0xFFFFFFFF
+
+
+def test_argument_errors(frt):
+    L = frt.lib()
+    b = frt.SceneBuilder()
+    with pytest.raises(frt.FrtError):
+        b.add_instance(0, 0, np.eye(4, dtype=np.float32))            # unknown mesh
+    with pytest.raises(frt.FrtError):
+        b.build()                                                   # no triangles
+    assert b"triangles" in L.frt_last_error()
+    g = frt.geometry.create_plane()
+    g.indices = np.array([0, 1, 7], np.uint32)
+    with pytest.raises(frt.FrtError):
+        b.add_mesh(g)                                               # index out of range
+    with pytest.raises(frt.FrtError):
+        frt.Renderer(b, 16, 16)                                     # scene not built
+    assert L.frt_renderer_render(None, None) < 0
+    assert L.frt_geometry_create(9, 0, None, None, None, None, None) < 0
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_cpu_fallback(frt):
+    """Without a HIP device the product refuses to render (FRT_ERR_NO_DEVICE) instead of falling back to the CPU."""
+    assert frt.lib().frt_device_count() == 0
+    s = frt.scenes.create_cornell_box()
+    with pytest.raises(frt.FrtError, match="no HIP device"):
+        frt.Renderer(s, 32, 32)
+
+
+def test_product_does_not_link_the_oracle():
+    """The product library and its Python mirror never reference oracle/ or tests/hostcheck."""
+    pkg = os.path.join(ROOT, "fast-raytracing-wgpu_amd")
+    for d, _, files in os.walk(pkg):
+        if os.sep + "lib" in d or "__pycache__" in d:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hpp", ".cpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(d, f)).read()
+                assert "oracle/" not in text and "liborc" not in text and "orc_" not in text, os.path.join(d, f)
+    out = os.popen(f"ldd {os.path.join(pkg, 'lib', 'libfrt.so')}").read()
+    assert "liborc" not in out and "hostcheck" not in out

@@ -1,0 +1,54 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo runs of the strip partition + halo exchange (frt.dist), with the oracle as
+the per-rank renderer, must reproduce the single-rank image bit for bit."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def run_ranks(mode, world, tmp_path, extra=()):
+    port = _free_port()
+    out = os.path.join(str(tmp_path), "res.json")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), "--mode", mode, "--rank", str(r), "--world", str(world),
+                               "--port", str(port), "--out", out, *extra], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return json.load(open(out))
+
+
+@pytest.mark.parametrize("world,H", [(2, 64), (3, 72)])
+def test_strip_partition_matches_single_rank(frt, orc, tmp_path, world, H):
+    res = run_ranks("oracle", world, tmp_path, ("--H", str(H), "--W", "80", "--frames", "4"))
+    assert res["ok"], res
+
+
+def test_strip_plan_geometry(frt):
+    from frt.dist import StripPlan
+    plans = [StripPlan(1080, 8, k) for k in range(8)]
+    assert plans[0].row_begin == 0 and plans[-1].row_end == 1080
+    assert all(a.row_end == b.row_begin for a, b in zip(plans, plans[1:]))
+    assert all(p.row_end - p.row_begin == 135 for p in plans)
+    # every send has a matching receive of the same rows on the peer
+    for f in (0, 3):
+        sends = {(p.rank, peer, buf, idx, s) for p in plans for peer, buf, idx, s, r in p.transfers(f)}
+        recvs = {(peer, p.rank, buf, idx, r) for p in plans for peer, buf, idx, s, r in p.transfers(f)}
+        assert sends == recvs
+    assert len(plans[0].transfers(0)) == 1 and len(plans[3].transfers(2)) == 4
+    with pytest.raises(ValueError):
+        StripPlan(64, 8, 0)

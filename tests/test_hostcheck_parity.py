@@ -1,0 +1,37 @@
+"""T3 (CPU leg): the product's stage functions, instantiated on the host by tests/hostcheck, against the oracle — every
+buffer of every frame, bit for bit. The -m gpu tests repeat this through the real kernels."""
+import numpy as np
+import pytest
+
+NAMES = {0: "gpos", 1: "gnormal", 2: "galbedo", 3: "gmotion", 4: "reservoir", 5: "raw", 6: "display", 7: "accum"}
+
+
+def _bits_equal(a, b):
+    return a.tobytes() == b.tobytes()
+
+
+def compare_all(got_reader, want_reader, frame, ctx=""):
+    for b in range(8):
+        for idx in ((0, 1) if b in (0, 1, 2, 4, 7) else (0,)):
+            g, w = got_reader(b, idx), want_reader(b, idx)
+            if not _bits_equal(g, w):
+                d = np.argwhere((g.view(np.uint32) != w.view(np.uint32)).any(axis=2))
+                raise AssertionError(f"{ctx} frame {frame} {NAMES[b]}[{idx}]: {len(d)} pixels differ, first at {tuple(d[0])}")
+
+
+@pytest.mark.parametrize("which,size,depth,frames,bvh", [("cornell", 64, 8, 4, True), ("cornell", 128, 1, 2, False),
+                                                         ("cornell", 48, 16, 2, True), ("restir", 48, 8, 3, True)])
+def test_stage_functions_match_oracle(frt, orc, hostcheck, which, size, depth, frames, bvh):
+    fs = frt.scenes.create_cornell_box() if which == "cornell" else frt.scenes.create_restir_scene()
+    os_ = orc.cornell() if which == "cornell" else orc.restir_scene()
+    os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    W, H = size, size * 3 // 4
+    ro = os_.renderer(W, H, depth, bvh, 8)       # bvh=False: BASELINE.json configs[0] (scalar loop over all triangles)
+    rh = hostcheck.renderer(fs, W, H, depth, 8)
+    for f in range(frames):
+        cam = frt.CameraController().build_uniform(W / H, f, fs.num_lights)
+        ro.render(cam); rh.render(cam)
+        compare_all(rh.read, ro.read, f, which)
+    st = ro.stats()["total"]
+    assert rh.rays() == (st["closest"], st["any"])
+    assert st["closest"] + st["any"] <= (4 + 2 * (2 * depth - 1)) * W * H * frames    # SURVEY §8(a) ray budget: 36 at MAX_DEPTH 8

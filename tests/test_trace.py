@@ -1,0 +1,84 @@
+"""T2: acceleration structures against the brute-force loop over all triangles (BASELINE.json configs[0])."""
+import numpy as np
+import pytest
+
+
+def _rays(n, seed, scene_box=1.0):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-0.98, 0.98, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    return o, d.astype(np.float32)
+
+
+def _edge_rays():
+    # axis-parallel rays, rays lying exactly in wall planes (d component == 0, origin on the plane), rays through shared
+    # triangle edges / vertices of the quads, and rays from the camera to the box corners
+    o, d = [], []
+    for y in (1.0, -1.0, 0.99):
+        for dz in (-1.0, 1.0):
+            o.append((1.0, y, 0.3474734)); d.append((-0.76039785, 0.0, dz * 0.64945745))
+            o.append((0.0, y, 0.0)); d.append((1.0, 0.0, 0.0)); o.append((0.0, y, 0.0)); d.append((0.0, 0.0, dz))
+    for a in range(3):
+        for sgn in (-1.0, 1.0):
+            v = [0.0, 0.0, 0.0]; v[a] = sgn
+            o.append((0.1, -0.2, 0.3)); d.append(tuple(v)); o.append((0.0, 0.0, 0.0)); d.append(tuple(v))
+    for cx in (-1.0, 0.0, 1.0):
+        for cy in (-1.0, 0.0, 1.0):
+            t = np.array([cx, cy, -1.0]) - np.array([0, 0, 3.0]); t /= np.linalg.norm(t)
+            o.append((0.0, 0.0, 3.0)); d.append(tuple(t))
+    o.append((0.0, -1.0, 0.0)); d.append((0.70710678, 0.0, -0.70710678))       # along the floor diagonal (shared edge)
+    return np.array(o, np.float32), np.array(d, np.float32)
+
+
+@pytest.mark.parametrize("which", ["cornell", "restir"])
+def test_bvh_equals_bruteforce(frt, orc, hostcheck, which):
+    fs = frt.scenes.create_cornell_box() if which == "cornell" else frt.scenes.create_restir_scene()
+    os_ = orc.cornell() if which == "cornell" else orc.restir_scene()
+    os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    n = 20000 if which == "cornell" else 3000
+    o, d = _rays(n, 7)
+    if which == "restir":
+        o = (o * np.array([5, 1, 5], np.float32)).astype(np.float32)
+    eo, ed = _edge_rays()
+    o = np.concatenate([o, eo]); d = np.concatenate([d, ed])
+    for tmin, tmax in ((0.001, 100.0), (0.0001, 0.7)):
+        tb, ib, uvb, fb, _ = os_.trace_closest(o, d, tmin, tmax, False)          # ground truth: loop over all triangles
+        tv, iv, uvv, fv, st = os_.trace_closest(o, d, tmin, tmax, True)          # oracle walk of the imported BVH2
+        th, ih, uvh, fh = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=False)   # product traversal (pair nodes), host build
+        for (t, i, uv, f) in ((tv, iv, uvv, fv), (th, ih, uvh, fh)):
+            assert np.array_equal(i, ib) and np.array_equal(t, tb)
+            hit = ib != 0xFFFFFFFF
+            assert np.array_equal(uv[hit], uvb[hit]) and np.array_equal(f[hit], fb[hit])
+        assert (ib != 0xFFFFFFFF).mean() > (0.2 if tmax > 1 else 0.02)
+        ob = os_.trace_any(o, d, tmin, tmax, False)
+        assert np.array_equal(os_.trace_any(o, d, tmin, tmax, True), ob)
+        _, ia, _, _ = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=True)
+        assert np.array_equal((ia != 0xFFFFFFFF).astype(np.uint8), ob)
+        assert np.array_equal(ob.astype(bool), tb >= 0)                           # any-hit <=> a closest hit exists
+
+
+def test_in_plane_reconnection_rays_are_not_lost(frt, orc, hostcheck):
+    """Regression: d.y == 0 with the origin on the ceiling plane (spatial-reuse visibility rays in corner pixels) used to
+    make the fma-form slab test evaluate inf - inf and drop the ceiling triangles."""
+    fs = frt.scenes.create_cornell_box(); os_ = orc.cornell()
+    o = np.array([[1.0, 1.0, 0.34747338]] * 4, np.float32)
+    d = np.array([[-0.76039785, 0, -0.64945745], [-0.08538333, 0, -0.9963482], [-0.3049969, 0, -0.95235336], [-0.8957124, 0, -0.4446341]], np.float32)
+    tmax = np.array([0.32927045, 0.03921813, 0.026023595, 0.24082603], np.float32)
+    want = os_.trace_any(o, d, 0.0001, tmax, False)
+    _, tri, _, _ = hostcheck.trace(fs, o, d, 0.0001, tmax, any_hit=True)
+    assert np.array_equal((tri != 0xFFFFFFFF).astype(np.uint8), want)
+
+
+def test_hit_semantics(orc):
+    s = orc.cornell()
+    o = np.array([[0.8, 0.5, 3], [0, 0, 3], [0, -0.999, 0]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, 1], [0, 1, 0]], np.float32)
+    t, tri, uv, fr, _ = s.trace_closest(o, d, 0.001, 1000.0, False)
+    assert t[0] == 4.0 and fr[0] == 1          # back wall at z = -1, front face towards the camera
+    assert t[1] == -1.0 and tri[1] == 0xFFFFFFFF   # open front: miss
+    ti = s.get("tri_instance")
+    assert ti[tri[2]] == 5 and abs(t[2] - 1.989) < 1e-5 and fr[2] == 1    # light quad at y = 0.99 faces down
+    # tmin / tmax are exclusive
+    t2, _, _, _, _ = s.trace_closest(o[:1], d[:1], 0.001, 4.0, False)
+    assert t2[0] == -1.0
