@@ -312,9 +312,9 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     } else {
         HIP_TRY(hipMalloc((void**)&r->arena, r->arena_bytes)); r->own_arena = true;
     }
-    HIP_TRY(hipMalloc((void**)&r->d_counters, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));   // wgpu zero-initialises textures and buffers
-    HIP_TRY(hipMemsetAsync(r->d_counters, 0, 2 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_counters, 0, 8 * sizeof(unsigned long long), r->stream));
     int rc = upload_scene(r, s->b);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -348,6 +348,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
     for (int stage = 0; stage < 4; ++stage) {
         if (!(phases & (1 << stage))) continue;
         fv.y0 = rows[2 * stage]; fv.y1 = rows[2 * stage + 1];
+        fv.ray_counters = r->d_counters + 2 * stage;
         frt_renderer::Timed t{};
         bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
         if (timed) {
@@ -390,7 +391,7 @@ int frt_renderer_clear(frt_renderer* r) {
     int rc = resolve_timing(r);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));
-    HIP_TRY(hipMemsetAsync(r->d_counters, 0, 2 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_counters, 0, 8 * sizeof(unsigned long long), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->frame_count = 0;
     memset(&r->stats, 0, sizeof(r->stats));
@@ -460,9 +461,13 @@ int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
     HIP_TRY(hipStreamSynchronize(r->stream));
     int rc = resolve_timing(r);
     if (rc) return rc;
-    unsigned long long c[2] = {0, 0};
+    unsigned long long c[8] = {0};
     HIP_TRY(hipMemcpy(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-    r->stats.rays_closest = c[0]; r->stats.rays_any = c[1];
+    r->stats.rays_closest = 0; r->stats.rays_any = 0;
+    for (int st = 0; st < 4; ++st) {
+        r->stats.rays_stage[st][0] = c[2 * st]; r->stats.rays_stage[st][1] = c[2 * st + 1];
+        r->stats.rays_closest += c[2 * st]; r->stats.rays_any += c[2 * st + 1];
+    }
     *out = r->stats;
     return FRT_OK;
 }

@@ -38,7 +38,7 @@ class RenderOpts(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("frames", C.c_uint64),
-                ("ms_stage", C.c_double * 4), ("launches", C.c_uint64 * 4)]
+                ("ms_stage", C.c_double * 4), ("launches", C.c_uint64 * 4), ("rays_stage", (C.c_uint64 * 2) * 4)]
 
 
 assert C.sizeof(VertexAttr) == 32 and C.sizeof(Material) == 64 and C.sizeof(Light) == 64 and C.sizeof(CameraUniform) == 288

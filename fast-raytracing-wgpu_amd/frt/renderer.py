@@ -93,4 +93,5 @@ class Renderer:
         s = Stats()
         check(lib().frt_renderer_stats(self._h, C.byref(s)))
         return {"rays_closest": s.rays_closest, "rays_any": s.rays_any, "frames": s.frames,
-                "ms_stage": list(s.ms_stage), "launches": list(s.launches)}
+                "ms_stage": list(s.ms_stage), "launches": list(s.launches),
+                "rays_stage": [[int(s.rays_stage[i][0]), int(s.rays_stage[i][1])] for i in range(4)]}

@@ -152,6 +152,7 @@ typedef struct frt_stats {
     uint64_t frames;          /* frames rendered since create/reset */
     double ms_stage[4];       /* summed kernel time per stage (gbuffer, temporal, spatial, post); FRT_FLAG_TIMING only */
     uint64_t launches[4];     /* launches per stage */
+    uint64_t rays_stage[4][2];/* per stage {closest, any}; post issues none */
 } frt_stats;
 
 uint64_t frt_renderer_arena_bytes(uint32_t width, uint32_t height);
