@@ -71,9 +71,12 @@ def test_full_size_properties(gpu, orc):
     bg = pos[..., 3] < 0
     raw = r.read_buffer(frt.BUF_RAW, 0)
     assert bg.any() and not res[bg].any() and not raw[bg].any() and acc[bg][:, :3].max() < 0.05
-    # light quad pixels integrate to exactly its emission (restir.wgsl:543-552): tonemap/inverse-tonemap round trip within 1e-4
+    # light quad pixels: trace_path returns exactly the emission (restir.wgsl:543-552) -> p_hat = 10, W = 1 in the spatial reservoir,
+    # radiance (10,10,10); the accumulated value is only near 10 (the bilateral filter mixes in ceiling pixels at the quad's rim)
     light = pos[..., 3] == 6.0
-    assert light.sum() > 1000 and np.abs(acc[light][:, :3] - 10.0).max() < 2e-3
+    rl = res[light].view(np.float32)
+    assert light.sum() > 1000 and np.all(rl[:, 7] == 10.0) and np.all(rl[:, 3] == 1.0)
+    assert np.all(raw[light].view(np.float16)[:, :3] == 10.0) and acc[light][:, :3].min() > 5.0
     assert np.all(acc[..., 3] == 1.0) and np.all(acc[..., :3] >= 0) and not np.isnan(acc).any()
     # ray budget: <= 36 rays per pixel per frame at MAX_DEPTH 8, and at least the primary ray
     rays = st["rays_closest"] + st["rays_any"]
