@@ -3,7 +3,7 @@
 // CPU test suite (-m "not gpu") can check the kernel bodies against the oracle before they ever run on an MI355X.
 // The kernels themselves (LDS stack columns, wave tiling, ray-counter reduction) are only exercised by the -m gpu tests.
 #include "../../fast-raytracing-wgpu_amd/csrc/frt_scene.hpp"
-#include "../../fast-raytracing-wgpu_amd/csrc/frt_shade.hpp"
+#include "../../fast-raytracing-wgpu_amd/csrc/frt_path.hpp"
 #include <vector>
 #include <cstring>
 #include <thread>
