@@ -5,7 +5,7 @@
 // (kStackDepth x 256 words = 32 KiB per workgroup; lane-consecutive addresses -> conflict-free ds_read/ds_write_b32).
 // Scene data (pair nodes 64 B, triangle slots 48 B) is read with 16-byte loads; per-pixel buffers are pixel-linear
 // float4 / 8-byte / 4-byte streams, so every wave-level access is a set of full 128-byte row segments.
-#include "frt_path.hpp"
+#include "frt_mono.hpp"
 #include "frt_kernels.hpp"
 #include <algorithm>
 
@@ -48,93 +48,179 @@ __global__ void __launch_bounds__(kBlock) gbuffer_kernel(SceneView sc, FrameView
     flush_ray_counters(fv, counted ? c.n_closest : 0u, counted ? c.n_any : 0u, s_cnt);
 }
 
-// Temporal (STAGE 1, trace_path variant 0) and spatial + shade (STAGE 2, variant 1) as a persistent wave-level state machine.
+// Opt-in (FRT_FLAG_COMPACTION) temporal (STAGE 1) / spatial + shade (STAGE 2) kernels: workgroup-level path compaction.
 //
-// Every lane carries one pixel's resumable state (frt_path.hpp). A lane whose pixel has finished is refilled at once from a
-// tile-ordered global queue: the idle lanes are found with a wave ballot, the leader takes popcount(ballot) queue slots
-// with ONE atomic, and each idle lane picks slot base + (its rank in the ballot). So the wave is kept compact — lanes at
-// different bounce depths, fresh lanes at depth 0 and (spatial) lanes still walking their neighbour list all share the two
-// traversal phases of an iteration:
-//     A  closest-hit rays of lanes at depth >= 1        C  any-hit rays: NEE shadow rays + spatial visibility rays
-//     B  shading up to the shadow ray / neighbour prep  D  NEE add + BSDF sample / reservoir merge; finalise finished pixels
-// Results do not depend on the order pixels are taken in: seeds are functions of (pixel, frame) only (restir.wgsl:797-798).
-enum : uint32_t { LANE_EMPTY = 0, LANE_NEIGH = 1, LANE_PATH = 2 };
+// One 512-thread workgroup (8 waves) owns a 32x16 pixel block, one wave per 8x8 tile, and runs the resumable path state
+// machine of frt_path.hpp one bounce per iteration:  A closest-hit rays -> B shade / NEE set-up -> C shadow rays -> D BSDF
+// sample, retire finished paths. Paths end at very different depths (roulette, light hits, the open front of the box), so
+// after a couple of bounces most lanes of every wave would idle (23 % lane utilisation measured on the thread-per-pixel
+// kernel, profiles/r1_v1_pmc_summary.md). Before each bounce the workgroup therefore takes a census with one wave ballot
+// per wave; whenever the surviving paths fit into fewer waves, each survivor computes its rank (ballot prefix + the counts
+// of the waves before it), parks its 24-32 words of path state in LDS at that rank, and the first ceil(live / 64) waves pick
+// the states up: the wave count shrinks 8 -> 4 -> 2 -> 1 as the paths die, and the remaining waves stay dense. The exchange
+// buffer is the traversal-stack memory (no ray is in flight at that point), so compaction costs no extra LDS.
+// A parked state carries its pixel index, so any lane can finish any pixel; results do not depend on the lane a path runs in.
+static constexpr int kBlockC = 512;
+static constexpr int kWavesC = kBlockC / 64;
+
+__device__ __forceinline__ void xput(uint32_t* x, uint32_t cap, uint32_t slot, int k, uint32_t v) { x[(uint32_t)k * cap + slot] = v; }
+__device__ __forceinline__ void xputf(uint32_t* x, uint32_t cap, uint32_t slot, int k, float v) { x[(uint32_t)k * cap + slot] = f2u(v); }
+__device__ __forceinline__ uint32_t xget(const uint32_t* x, uint32_t cap, uint32_t slot, int k) { return x[(uint32_t)k * cap + slot]; }
+__device__ __forceinline__ float xgetf(const uint32_t* x, uint32_t cap, uint32_t slot, int k) { return u2f(x[(uint32_t)k * cap + slot]); }
 
 template <int STAGE>
-__global__ void __launch_bounds__(kBlock) wavefront_kernel(SceneView sc, FrameView fv, uint32_t* queue) {
+__device__ __forceinline__ void park_state(uint32_t* x, uint32_t cap, uint32_t slot, const PathState& st, uint32_t rng, bool owned, const ReservoirView& r) {
+    xput(x, cap, slot, 0, st.pix); xput(x, cap, slot, 1, st.depth);
+    xput(x, cap, slot, 2, (st.prev_diffuse ? 1u : 0u) | (st.is_glass ? 2u : 0u) | (st.front_face ? 4u : 0u) | (owned ? 8u : 0u));
+    xput(x, cap, slot, 3, rng);
+    xputf(x, cap, slot, 4, st.pos.x); xputf(x, cap, slot, 5, st.pos.y); xputf(x, cap, slot, 6, st.pos.z);
+    xputf(x, cap, slot, 7, st.ffnormal.x); xputf(x, cap, slot, 8, st.ffnormal.y); xputf(x, cap, slot, 9, st.ffnormal.z);
+    xputf(x, cap, slot, 10, st.throughput.x); xputf(x, cap, slot, 11, st.throughput.y); xputf(x, cap, slot, 12, st.throughput.z);
+    xputf(x, cap, slot, 13, st.accum.x); xputf(x, cap, slot, 14, st.accum.y); xputf(x, cap, slot, 15, st.accum.z);
+    xputf(x, cap, slot, 16, st.next_dir.x); xputf(x, cap, slot, 17, st.next_dir.y); xputf(x, cap, slot, 18, st.next_dir.z);
+    xputf(x, cap, slot, 19, st.v1_pos.x); xputf(x, cap, slot, 20, st.v1_pos.y); xputf(x, cap, slot, 21, st.v1_pos.z);
+    xputf(x, cap, slot, 22, st.hit_t); xputf(x, cap, slot, 23, st.last_pdf);
+    if (STAGE == 2) {
+        xput(x, cap, slot, 24, r.y); xputf(x, cap, slot, 25, r.w_sum); xput(x, cap, slot, 26, r.M); xputf(x, cap, slot, 27, r.W);
+        xputf(x, cap, slot, 28, r.sx); xputf(x, cap, slot, 29, r.sy); xputf(x, cap, slot, 30, r.sz); xputf(x, cap, slot, 31, r.p_hat);
+    }
+}
+template <int STAGE>
+__device__ __forceinline__ void fetch_state(const uint32_t* x, uint32_t cap, uint32_t slot, PathState& st, uint32_t& rng, bool& owned, ReservoirView& r) {
+    st.pix = xget(x, cap, slot, 0); st.depth = xget(x, cap, slot, 1);
+    uint32_t fl = xget(x, cap, slot, 2);
+    st.prev_diffuse = fl & 1u; st.is_glass = fl & 2u; st.front_face = fl & 4u; owned = fl & 8u;
+    rng = xget(x, cap, slot, 3);
+    st.pos = mk3(xgetf(x, cap, slot, 4), xgetf(x, cap, slot, 5), xgetf(x, cap, slot, 6));
+    st.ffnormal = mk3(xgetf(x, cap, slot, 7), xgetf(x, cap, slot, 8), xgetf(x, cap, slot, 9));
+    st.throughput = mk3(xgetf(x, cap, slot, 10), xgetf(x, cap, slot, 11), xgetf(x, cap, slot, 12));
+    st.accum = mk3(xgetf(x, cap, slot, 13), xgetf(x, cap, slot, 14), xgetf(x, cap, slot, 15));
+    st.next_dir = mk3(xgetf(x, cap, slot, 16), xgetf(x, cap, slot, 17), xgetf(x, cap, slot, 18));
+    st.v1_pos = mk3(xgetf(x, cap, slot, 19), xgetf(x, cap, slot, 20), xgetf(x, cap, slot, 21));
+    st.hit_t = xgetf(x, cap, slot, 22); st.last_pdf = xgetf(x, cap, slot, 23);
+    st.done = false;
+    if (STAGE == 2) {
+        r.y = xget(x, cap, slot, 24); r.w_sum = xgetf(x, cap, slot, 25); r.M = xget(x, cap, slot, 26); r.W = xgetf(x, cap, slot, 27);
+        r.sx = xgetf(x, cap, slot, 28); r.sy = xgetf(x, cap, slot, 29); r.sz = xgetf(x, cap, slot, 30); r.p_hat = xgetf(x, cap, slot, 31);
+    }
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(kBlockC) compact_kernel(SceneView sc, FrameView fv) {
+    __shared__ uint32_t s_mem[kStackDepth * kBlockC];   // per-lane traversal stacks; the exchange buffer while compacting
+    __shared__ uint32_t s_live[2][kWavesC];
+    __shared__ uint32_t s_cnt[2];
+    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    if (tid < 2u) s_cnt[tid] = 0u;
+    const uint32_t px = blockIdx.x * 32u + (wave & 3u) * 8u + (lane & 7u);
+    const uint32_t py = fv.y0 + blockIdx.y * 16u + (wave >> 2) * 8u + (lane >> 3);
+    PathCtx c(sc, fv, &s_mem[tid], (uint32_t)kBlockC);
+    PathState st;
+    SpatialState ss;
+    ReservoirView r = zero_reservoir();
+    st.done = true; st.depth = 0u; st.pix = 0u;
+    bool alive = false, owned = false;
+    uint32_t n_closest = 0u, n_any = 0u;
+
+    if (px < fv.W && py < fv.y1) {
+        const uint32_t pix = py * fv.W + px;
+        owned = py >= fv.own_y0 && py < fv.own_y1;
+        if (STAGE == 1) alive = temporal_begin(c, st, pix);
+        else if (spatial_begin(c, ss, pix)) {
+            // neighbour loop (restir_spatial.wgsl:912-993): coherent across the tile, stays in its lane
+            while (ss.i < ss.n) {
+                AnyReq req;
+                req.want = false; req.o = splat3(0.0f); req.d = splat3(0.0f); req.tmin = 0.0f; req.tmax = 0.0f;
+                spatial_neighbor_prepare(c, ss, req);
+                bool visible = true;
+                if (req.want) {
+                    HitRec s;
+                    if (owned) n_any++;
+                    trace<true>(sc, req.o, req.d, req.tmin, req.tmax, c.stk, c.stride, s);
+                    visible = s.tri == 0xFFFFFFFFu;
+                }
+                spatial_neighbor_finish(ss, visible);
+            }
+            r = ss.r;
+            path_begin(c, st, pix, r.y);
+            alive = true;
+        }
+    }
+
+    uint32_t cur_waves = kWavesC;
+    for (uint32_t it = 0;; ++it) {
+        // ---- census: one ballot per wave, counts shared through LDS (double-buffered: one barrier per iteration)
+        const unsigned long long m = __ballot(alive);
+        uint32_t* live = s_live[it & 1u];
+        if (lane == 0u) live[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t total = 0u, base = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < (uint32_t)kWavesC; ++w) { uint32_t v = live[w]; total += v; base += (w < wave) ? v : 0u; }
+        if (total == 0u) break;
+        const uint32_t new_waves = (total + 63u) >> 6;
+        if (new_waves < cur_waves) {
+            // ---- compaction: survivors park their state at their rank; the first new_waves waves pick the states up
+            const uint32_t cap = new_waves * 64u;
+            if (alive) {
+                uint32_t rank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                park_state<STAGE>(s_mem, cap, rank, st, c.rng, owned, r);
+            }
+            __syncthreads();
+            alive = tid < total;
+            if (alive) fetch_state<STAGE>(s_mem, cap, tid, st, c.rng, owned, r);
+            cur_waves = new_waves;
+            __syncthreads();   // the exchange buffer becomes stack memory again
+        }
+        if (!alive) continue;   // whole idle waves only meet the barriers
+
+        // ---- A: closest-hit ray of this bounce (depth >= 1; the depth-0 hit is the G-buffer)
+        HitRec h;
+        h.tri = 0xFFFFFFFFu; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.inst = 0u; h.front = false;
+        f3 origin = splat3(0.0f);
+        if (st.depth >= 1u) {
+            if (path_pre_closest(c, st, origin)) {
+                if (owned) n_closest++;
+                trace<false>(sc, origin, st.next_dir, 0.001f, 100.0f, c.stk, c.stride, h);
+            }
+        }
+        // ---- B: shade up to the shadow ray
+        AnyReq req;
+        req.want = false; req.o = splat3(0.0f); req.d = splat3(0.0f); req.tmin = 0.0f; req.tmax = 0.0f;
+        if (!st.done) path_shade<VARIANT>(c, st, h, origin, req);
+        // ---- C: NEE shadow ray
+        bool visible = true;
+        if (req.want) {
+            HitRec s;
+            if (owned) n_any++;
+            trace<true>(sc, req.o, req.d, req.tmin, req.tmax, c.stk, c.stride, s);
+            visible = s.tri == 0xFFFFFFFFu;
+        }
+        // ---- D: NEE add + BSDF sample; retire finished paths
+        if (!st.done) path_post_any(c, st, visible);
+        if (st.done) {
+            if (STAGE == 1) temporal_finalize(c, st);
+            else { ss.r = r; ss.pix = st.pix; spatial_finalize(c, ss, st); }
+            alive = false;
+        }
+    }
+    flush_ray_counters(fv, n_closest, n_any, s_cnt);
+}
+
+// Default temporal / spatial kernels: one thread per pixel, straight-line trace_path (frt_mono.hpp). Fastest measured form.
+template <int STAGE>
+__global__ void __launch_bounds__(kBlock) pixel_kernel(SceneView sc, FrameView fv) {
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     __shared__ uint32_t s_cnt[2];
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
-    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
-    const uint32_t tiles_x = (fv.W + 7u) >> 3, tiles_y = (fv.y1 - fv.y0 + 7u) >> 3;
-    const uint32_t total = tiles_x * tiles_y * 64u;
+    uint32_t px, py;
+    bool active = tile_pixel(fv, px, py);
     PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
-    PathState st;
-    SpatialState ss;
-    st.done = true; st.depth = 0u; ss.i = 0u; ss.n = 0u;
-    uint32_t mode = LANE_EMPTY, tot_closest = 0u, tot_any = 0u;
-    bool exhausted = false, owned = false;
-
-    for (;;) {
-        // ---- regeneration (ballot compaction): idle lanes pull pixels until each has work or the queue is dry
-        while (mode == LANE_EMPTY && !exhausted) {
-            unsigned long long idle = __ballot(1);
-            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            uint32_t base = 0u;
-            if (rank == 0u) base = atomicAdd(queue, (uint32_t)__popcll(idle));
-            base = __shfl(base, __ffsll((long long)idle) - 1, 64);
-            uint32_t idx = base + rank;
-            if (idx >= total) { exhausted = true; break; }
-            uint32_t tile = idx >> 6, l = idx & 63u;
-            uint32_t px = (tile % tiles_x) * 8u + (l & 7u);
-            uint32_t py = fv.y0 + (tile / tiles_x) * 8u + (l >> 3);
-            if (px >= fv.W || py >= fv.y1) continue;
-            uint32_t pix = py * fv.W + px;
-            owned = py >= fv.own_y0 && py < fv.own_y1;
-            if (STAGE == 1) { if (temporal_begin(c, st, pix)) mode = LANE_PATH; }
-            else { if (spatial_begin(c, ss, pix)) mode = ss.n > 0u ? LANE_NEIGH : LANE_PATH; }
-        }
-        if (!__any(mode != LANE_EMPTY)) break;   // every lane idle => every lane saw the queue dry
-
-        // ---- A: closest-hit rays
-        HitRec h;
-        h.tri = 0xFFFFFFFFu; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.inst = 0u; h.front = false;
-        f3 origin = splat3(0.0f);
-        if (mode == LANE_PATH && st.depth >= 1u) {
-            if (path_pre_closest(c, st, origin)) {
-                c.n_closest++;
-                trace<false>(sc, origin, st.next_dir, 0.001f, 100.0f, c.stk, c.stride, h);
-            }
-        }
-        // ---- B: shade up to the shadow ray / prepare the next spatial neighbour
-        AnyReq req;
-        req.want = false; req.o = splat3(0.0f); req.d = splat3(0.0f); req.tmin = 0.0f; req.tmax = 0.0f;
-        if (mode == LANE_PATH) { if (!st.done) path_shade<VARIANT>(c, st, h, origin, req); }
-        else if (STAGE == 2 && mode == LANE_NEIGH) spatial_neighbor_prepare(c, ss, req);
-        // ---- C: any-hit rays (NEE shadow rays and reconnection visibility rays together)
-        bool visible = true;
-        if (req.want) {
-            HitRec s;
-            c.n_any++;
-            trace<true>(sc, req.o, req.d, req.tmin, req.tmax, c.stk, c.stride, s);
-            visible = s.tri == 0xFFFFFFFFu;
-        }
-        // ---- D: finish the step; retire finished pixels
-        if (mode == LANE_PATH) {
-            if (!st.done) path_post_any(c, st, visible);
-            if (st.done) {
-                if (STAGE == 1) temporal_finalize(c, st); else spatial_finalize(c, ss, st);
-                if (owned) { tot_closest += c.n_closest; tot_any += c.n_any; }
-                c.n_closest = 0u; c.n_any = 0u;
-                mode = LANE_EMPTY;
-            }
-        } else if (STAGE == 2 && mode == LANE_NEIGH) {
-            spatial_neighbor_finish(ss, visible);
-            if (ss.i >= ss.n) { path_begin(c, st, ss.pix, ss.r.y); mode = LANE_PATH; }
-        }
-    }
-    flush_ray_counters(fv, tot_closest, tot_any, s_cnt);
+    if (active) { if (STAGE == 1) temporal_pixel(c, px, py); else spatial_pixel(c, px, py); }
+    bool counted = active && py >= fv.own_y0 && py < fv.own_y1;
+    flush_ray_counters(fv, counted ? c.n_closest : 0u, counted ? c.n_any : 0u, s_cnt);
 }
 
 __global__ void __launch_bounds__(kBlock) post_kernel(FrameView fv) {
@@ -144,25 +230,20 @@ __global__ void __launch_bounds__(kBlock) post_kernel(FrameView fv) {
 
 static dim3 grid_for(const FrameView& fv) { return dim3((fv.W + 15u) / 16u, (fv.y1 - fv.y0 + 15u) / 16u, 1u); }
 
-// Resident workgroups per CU of the persistent kernels (VGPR / LDS limited); the grid is CUs x this, so every workgroup is
-// resident from the start and the queue drains evenly. (No workgroup waits on another: a smaller residency only adds a tail.)
-uint32_t persistent_blocks_per_cu(int stage) {
-    int n = 0;
-    hipError_t e = stage == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wavefront_kernel<1>, kBlock, 0)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wavefront_kernel<2>, kBlock, 0);
-    if (e != hipSuccess || n < 1) n = 2;
-    return (uint32_t)n;
-}
-
-hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, uint32_t* queue, uint32_t persistent_blocks) {
+hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, bool compaction) {
     if (fv.y1 <= fv.y0 || fv.W == 0u) return hipSuccess;
     dim3 grid = grid_for(fv), block(kBlock);
-    uint32_t tiles = ((fv.W + 7u) / 8u) * ((fv.y1 - fv.y0 + 7u) / 8u);
-    dim3 pgrid(std::max(1u, std::min(persistent_blocks, (tiles + 3u) / 4u)));
+    dim3 cgrid((fv.W + 31u) / 32u, (fv.y1 - fv.y0 + 15u) / 16u, 1u), cblock(kBlockC);
     switch (stage) {
     case 0: hipLaunchKernelGGL(gbuffer_kernel, grid, block, 0, stream, sc, fv); break;
-    case 1: hipLaunchKernelGGL(wavefront_kernel<1>, pgrid, block, 0, stream, sc, fv, queue); break;
-    case 2: hipLaunchKernelGGL(wavefront_kernel<2>, pgrid, block, 0, stream, sc, fv, queue); break;
+    case 1:
+        if (compaction) hipLaunchKernelGGL(compact_kernel<1>, cgrid, cblock, 0, stream, sc, fv);
+        else hipLaunchKernelGGL(pixel_kernel<1>, grid, block, 0, stream, sc, fv);
+        break;
+    case 2:
+        if (compaction) hipLaunchKernelGGL(compact_kernel<2>, cgrid, cblock, 0, stream, sc, fv);
+        else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv);
+        break;
     case 3: hipLaunchKernelGGL(post_kernel, grid, block, 0, stream, fv); break;
     default: return hipErrorInvalidValue;
     }

@@ -26,7 +26,9 @@ struct PathState {
     // live across the any-hit phase
     f3 wo, base_color;
     MatParams m;
-    f3 nee_value;
+    // NEE sample waiting for its shadow ray: direction, geometry terms, MIS weight, emission
+    f3 nee_L, nee_Le;
+    float nee_gw, nee_w;   // geometry term G and MIS weight / pdf
     uint32_t nee;
 };
 
@@ -35,7 +37,7 @@ FRT_HD void path_begin(PathCtx& c, PathState& st, uint32_t pix, uint32_t seed) {
     st.pix = pix; st.depth = 0u; st.done = false; st.prev_diffuse = false; st.is_glass = false; st.front_face = true;
     st.pos = splat3(0.0f); st.ffnormal = splat3(0.0f); st.hit_t = 0.0f;
     st.throughput = splat3(1.0f); st.accum = splat3(0.0f); st.next_dir = splat3(0.0f); st.v1_pos = splat3(0.0f);
-    st.last_pdf = 0.0f; st.nee = NEE_NONE; st.nee_value = splat3(0.0f);
+    st.last_pdf = 0.0f; st.nee = NEE_NONE; st.nee_L = splat3(0.0f); st.nee_Le = splat3(0.0f); st.nee_gw = 0.0f; st.nee_w = 0.0f;
     st.wo = splat3(0.0f); st.base_color = splat3(0.0f);
     st.m.roughness = 0.0f; st.m.metallic = 0.0f; st.m.transmission = 0.0f; st.m.ior = 1.0f;
 }
@@ -53,8 +55,8 @@ FRT_HD bool path_pre_closest(PathCtx& c, PathState& st, f3& origin) {
     return true;
 }
 
-// NEE set-up shared by the primary hit and every bounce (restir.wgsl:558-571 == :707-720 + eval_direct_lighting :443-459).
-// The BSDF value is evaluated before the shadow ray instead of after it: it is a pure function, so the sum is unchanged.
+// NEE set-up shared by the primary hit and every bounce (restir.wgsl:558-571 == :707-720 + eval_direct_lighting :443-459),
+// up to the shadow ray; nee_finish evaluates the BSDF only for unoccluded samples, like the reference.
 template <int VARIANT>
 FRT_HD void nee_prepare(PathCtx& c, PathState& st, AnyReq& req) {
     st.nee = NEE_NONE;
@@ -74,9 +76,8 @@ FRT_HD void nee_prepare(PathCtx& c, PathState& st, AnyReq& req) {
     float l_dot_n = fmaxn(dot(-L, ls.normal), 0.0f);
     st.nee = NEE_ZERO;
     if (n_dot_l > 0.0f && l_dot_n > 0.0f) {
-        f3 f = eval_bsdf(st.ffnormal, L, st.wo, st.m, st.base_color);
         float G = (n_dot_l * l_dot_n) / (dist * dist);
-        st.nee_value = xyz(ls.emission) * ls.emission.w * f * G * weight;
+        st.nee_L = L; st.nee_Le = xyz(ls.emission) * ls.emission.w; st.nee_gw = G; st.nee_w = weight;
         // trace_shadow_ray: restir.wgsl:375-381 (VARIANT 0) vs restir_spatial.wgsl:380-400 (VARIANT 1)
         float t_max = fmaxn(dist * 0.999f, 0.0f);
         float t_min = VARIANT == 0 ? 0.001f : 0.0001f;
@@ -196,7 +197,11 @@ FRT_HD void path_shade(PathCtx& c, PathState& st, const HitRec& h, f3 origin, An
 FRT_HD void path_post_any(PathCtx& c, PathState& st, bool visible) {
     if (st.nee != NEE_NONE) {
         bool lit = (st.nee == NEE_VISIBLE) || (st.nee == NEE_TRACE && visible);
-        f3 direct = lit ? st.nee_value : splat3(0.0f);
+        f3 direct = splat3(0.0f);
+        if (lit) {   // eval_direct_lighting :453-455: Le * f * G * weight
+            f3 f = eval_bsdf(st.ffnormal, st.nee_L, st.wo, st.m, st.base_color);
+            direct = st.nee_Le * f * st.nee_gw * st.nee_w;
+        }
         st.accum = st.accum + direct * st.throughput;
     }
     BsdfSmp s = sample_bsdf(c, st.wo, st.ffnormal, st.front_face, st.m, st.base_color);
@@ -450,13 +455,13 @@ FRT_HD void run_path(PathCtx& c, PathState& st) {
         path_post_any(c, st, visible);
     }
 }
-FRT_HD void temporal_pixel(PathCtx& c, uint32_t px, uint32_t py) {
+FRT_HD void temporal_pixel_sm(PathCtx& c, uint32_t px, uint32_t py) {
     PathState st;
     if (!temporal_begin(c, st, px + py * c.fv.W)) return;
     run_path<0>(c, st);
     temporal_finalize(c, st);
 }
-FRT_HD void spatial_pixel(PathCtx& c, uint32_t px, uint32_t py) {
+FRT_HD void spatial_pixel_sm(PathCtx& c, uint32_t px, uint32_t py) {
     SpatialState ss;
     if (!spatial_begin(c, ss, py * c.fv.W + px)) return;
     while (ss.i < ss.n) {

@@ -45,8 +45,6 @@ struct frt_renderer {
     size_t arena_bytes = 0;
     size_t off[B_COUNT] = {};
     unsigned long long* d_counters = nullptr;
-    uint32_t* d_queues = nullptr;          // work-queue heads of the persistent stages, [stage]
-    uint32_t persistent_blocks[4] = {0, 768, 768, 0};
     frt_stats stats{};
     struct Timed { hipEvent_t a, b; int stage; };
     std::vector<Timed> pending;
@@ -294,7 +292,6 @@ void frt_renderer_destroy(frt_renderer* r) {
     for (void* p : r->scene_allocs) (void)hipFree(p);
     if (r->own_arena && r->arena) (void)hipFree(r->arena);
     if (r->d_counters) (void)hipFree(r->d_counters);
-    if (r->d_queues) (void)hipFree(r->d_queues);
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -316,10 +313,6 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         HIP_TRY(hipMalloc((void**)&r->arena, r->arena_bytes)); r->own_arena = true;
     }
     HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void**)&r->d_queues, 4 * sizeof(uint32_t)));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, r->device));
-    for (int st = 1; st <= 2; ++st) r->persistent_blocks[st] = (uint32_t)prop.multiProcessorCount * persistent_blocks_per_cu(st);
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));   // wgpu zero-initialises textures and buffers
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, 8 * sizeof(unsigned long long), r->stream));
     int rc = upload_scene(r, s->b);
@@ -352,7 +345,6 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
     fill_frame_view(r, cam, fv);
     uint32_t rows[8];
     phase_rows(r, rows);
-    if (phases & (FRT_PHASE_TEMPORAL | FRT_PHASE_SPATIAL)) HIP_TRY(hipMemsetAsync(r->d_queues, 0, 4 * sizeof(uint32_t), r->stream));
     for (int stage = 0; stage < 4; ++stage) {
         if (!(phases & (1 << stage))) continue;
         fv.y0 = rows[2 * stage]; fv.y1 = rows[2 * stage + 1];
@@ -363,7 +355,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
             HIP_TRY(hipEventCreate(&t.a)); HIP_TRY(hipEventCreate(&t.b)); t.stage = stage;
             HIP_TRY(hipEventRecord(t.a, r->stream));
         }
-        HIP_TRY(launch_stage(stage, r->sv, fv, r->stream, r->d_queues + stage, r->persistent_blocks[stage]));
+        HIP_TRY(launch_stage(stage, r->sv, fv, r->stream, (r->flags & FRT_FLAG_COMPACTION) != 0));
         if (timed) { HIP_TRY(hipEventRecord(t.b, r->stream)); r->pending.push_back(t); }
         r->stats.launches[stage] += 1;
     }

@@ -130,7 +130,9 @@ typedef struct frt_render_opts {
     uint32_t flags;           /* FRT_FLAG_* */
     uint32_t reserved;
 } frt_render_opts;
-#define FRT_FLAG_TIMING 1u    /* record per-stage HIP events every frame (frt_stats.ms_*) */
+#define FRT_FLAG_TIMING 1u          /* record per-stage HIP events every frame (frt_stats.ms_*) */
+#define FRT_FLAG_COMPACTION 2u      /* temporal / spatial stages through the workgroup-compacting kernels (opt-in: measured slower than
+                                       one thread per pixel on the Cornell Box, profiles/r1_v3_*; same pixels either way) */
 
 enum { FRT_PHASE_GBUFFER = 1, FRT_PHASE_TEMPORAL = 2, FRT_PHASE_SPATIAL = 4, FRT_PHASE_POST = 8, FRT_PHASE_ALL = 15 };
 

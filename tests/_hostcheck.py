@@ -11,13 +11,13 @@ class HostCheck:
         P, U32 = C.c_void_p, C.c_uint32
         L.hc_create.restype = P; L.hc_create.argtypes = [P, U32, U32, U32, C.c_int]
         L.hc_destroy.argtypes = [P]
-        L.hc_render.argtypes = [P, P]
+        L.hc_render.argtypes = [P, P, C.c_int]
         L.hc_read.restype = C.c_int; L.hc_read.argtypes = [P, C.c_int, C.c_int, P]
         L.hc_rays.argtypes = [P, P]
         L.hc_trace.argtypes = [P, C.c_int, U32, P, P, C.c_float, P, P, P, P, P]
 
-    def renderer(self, scene, w, h, max_depth=8, nthreads=8):
-        return HcRenderer(self, scene, w, h, max_depth, nthreads)
+    def renderer(self, scene, w, h, max_depth=8, nthreads=8, state_machine=False):
+        return HcRenderer(self, scene, w, h, max_depth, nthreads, state_machine)
 
     def trace(self, scene, o, d, tmin, tmax, any_hit=False):
         o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); n = o.shape[0]
@@ -29,8 +29,8 @@ class HostCheck:
 
 
 class HcRenderer:
-    def __init__(self, hc, scene, w, h, max_depth, nthreads):
-        self.L, self.scene, self.w, self.hgt = hc.L, scene, w, h
+    def __init__(self, hc, scene, w, h, max_depth, nthreads, state_machine=False):
+        self.L, self.scene, self.w, self.hgt, self.sm = hc.L, scene, w, h, int(state_machine)
         self.h = self.L.hc_create(scene._h, w, h, max_depth, nthreads)
 
     def __del__(self):
@@ -39,7 +39,7 @@ class HcRenderer:
 
     def render(self, cam):
         cam = np.ascontiguousarray(np.frombuffer(bytes(cam), np.uint8))
-        self.L.hc_render(self.h, cam.ctypes.data)
+        self.L.hc_render(self.h, cam.ctypes.data, self.sm)
 
     def read(self, buf, index=0):
         out = np.zeros((self.hgt, self.w, BPP[buf]), np.uint8)

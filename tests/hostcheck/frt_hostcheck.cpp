@@ -3,7 +3,7 @@
 // CPU test suite (-m "not gpu") can check the kernel bodies against the oracle before they ever run on an MI355X.
 // The kernels themselves (LDS stack columns, wave tiling, ray-counter reduction) are only exercised by the -m gpu tests.
 #include "../../fast-raytracing-wgpu_amd/csrc/frt_scene.hpp"
-#include "../../fast-raytracing-wgpu_amd/csrc/frt_path.hpp"
+#include "../../fast-raytracing-wgpu_amd/csrc/frt_mono.hpp"
 #include <vector>
 #include <cstring>
 #include <thread>
@@ -56,7 +56,8 @@ void* hc_create(const frt_scene* s, uint32_t W, uint32_t H, uint32_t max_depth, 
 }
 void hc_destroy(void* p) { delete (HostCheck*)p; }
 
-void hc_render(void* p, const frt_camera_uniform* cam) {
+// sm != 0: drive the resumable state machine (frt_path.hpp) instead of the straight-line functions (frt_mono.hpp)
+void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     HostCheck* h = (HostCheck*)p;
     uint32_t cur = h->frame_count & 1u, prv = cur ^ 1u;
     FrameView fv{};
@@ -76,8 +77,8 @@ void hc_render(void* p, const frt_camera_uniform* cam) {
                 for (uint32_t x = 0; x < h->W; ++x) {
                     PathCtx c(h->sv, fv, stack, 1u);
                     if (stage == 0) gbuffer_pixel(c, x, y);
-                    else if (stage == 1) temporal_pixel(c, x, y);
-                    else if (stage == 2) spatial_pixel(c, x, y);
+                    else if (stage == 1) { if (sm) temporal_pixel_sm(c, x, y); else temporal_pixel(c, x, y); }
+                    else if (stage == 2) { if (sm) spatial_pixel_sm(c, x, y); else spatial_pixel(c, x, y); }
                     else post_pixel(fv, x, y);
                     rc[2 * tid] += c.n_closest; rc[2 * tid + 1] += c.n_any;
                 }

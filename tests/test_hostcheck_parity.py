@@ -19,15 +19,16 @@ def compare_all(got_reader, want_reader, frame, ctx=""):
                 raise AssertionError(f"{ctx} frame {frame} {NAMES[b]}[{idx}]: {len(d)} pixels differ, first at {tuple(d[0])}")
 
 
+@pytest.mark.parametrize("sm", [False, True], ids=["straight", "state_machine"])
 @pytest.mark.parametrize("which,size,depth,frames,bvh", [("cornell", 64, 8, 4, True), ("cornell", 128, 1, 2, False),
                                                          ("cornell", 48, 16, 2, True), ("restir", 48, 8, 3, True)])
-def test_stage_functions_match_oracle(frt, orc, hostcheck, which, size, depth, frames, bvh):
+def test_stage_functions_match_oracle(frt, orc, hostcheck, which, size, depth, frames, bvh, sm):
     fs = frt.scenes.create_cornell_box() if which == "cornell" else frt.scenes.create_restir_scene()
     os_ = orc.cornell() if which == "cornell" else orc.restir_scene()
     os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
     W, H = size, size * 3 // 4
     ro = os_.renderer(W, H, depth, bvh, 8)       # bvh=False: BASELINE.json configs[0] (scalar loop over all triangles)
-    rh = hostcheck.renderer(fs, W, H, depth, 8)
+    rh = hostcheck.renderer(fs, W, H, depth, 8, state_machine=sm)   # frt_mono.hpp (default kernels) or frt_path.hpp (compacting kernels)
     for f in range(frames):
         cam = frt.CameraController().build_uniform(W / H, f, fs.num_lights)
         ro.render(cam); rh.render(cam)

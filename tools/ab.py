@@ -1,0 +1,20 @@
+"""A/B timing of kernel variants in ONE process (interleaved rounds): compaction on/off at 1920x1080."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fast-raytracing-wgpu_amd"))
+import frt
+W, H = 1920, 1080
+scene = frt.scenes.create_cornell_box()
+cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(40)]
+rs = {"pixel": frt.Renderer(scene, W, H, flags=frt.FLAG_TIMING), "compaction": frt.Renderer(scene, W, H, flags=frt.FLAG_TIMING | frt.FLAG_COMPACTION)}
+print(scene.bvh_stats())
+for rnd in range(2):
+    for k, r in rs.items():
+        r.clear()
+        for f in range(8): r.render(cams[f])
+        r.sync(); s0 = r.stats(); t0 = time.perf_counter()
+        for f in range(8, 40): r.render(cams[f])
+        r.sync(); t1 = time.perf_counter(); s1 = r.stats()
+        rays = s1["rays_closest"] + s1["rays_any"] - s0["rays_closest"] - s0["rays_any"]
+        ms = [(a - b) / 32 for a, b in zip(s1["ms_stage"], s0["ms_stage"])]
+        print(f"round {rnd} {k:8s} {(t1 - t0) / 32 * 1e3:.3f} ms/frame {rays / (t1 - t0) / 1e6:.0f} Mrays/s stages " + " ".join(f"{m:.3f}" for m in ms), flush=True)
