@@ -287,7 +287,7 @@ uint64_t frt_renderer_arena_bytes(uint32_t width, uint32_t height) { return aren
 void frt_renderer_destroy(frt_renderer* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
-    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    (void)hipStreamSynchronize(r->stream);
     for (auto& t : r->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (void* p : r->scene_allocs) (void)hipFree(p);
     if (r->own_arena && r->arena) (void)hipFree(r->arena);
@@ -302,7 +302,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         return fail(FRT_ERR_NO_DEVICE, "no HIP device: this library has no CPU rendering path");
     if (r->device < 0 || r->device >= ndev) return fail(FRT_ERR_INVALID_ARG, "device ordinal out of range");
     HIP_TRY(hipSetDevice(r->device));
-    if (o && o->stream) { r->stream = (hipStream_t)o->stream; r->own_stream = false; }
+    if (o && (o->stream || (o->flags & FRT_FLAG_USE_STREAM))) { r->stream = (hipStream_t)o->stream; r->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); r->own_stream = true; }
     r->arena_bytes = arena_layout(r->W, r->H, r->off);
     if (o && o->device_arena) {

@@ -1,7 +1,7 @@
 """Renderer mirror (src/renderer.rs) over frt_renderer_*. Every pixel is produced by the HIP kernels in libfrt.so."""
 import ctypes as C
 import numpy as np
-from ._lib import (lib, check, FrtError, RenderOpts, Stats, CameraUniform, BUF_BPP, BUF_ACCUM, BUF_DISPLAY, PHASE_ALL)
+from ._lib import (lib, check, FrtError, RenderOpts, Stats, CameraUniform, BUF_BPP, BUF_ACCUM, BUF_DISPLAY, PHASE_ALL, FLAG_USE_STREAM)
 
 
 class Renderer:
@@ -9,7 +9,9 @@ class Renderer:
         """Renderer::new (renderer.rs:206). rows=(begin,end) restricts this renderer to an image strip."""
         o = RenderOpts()
         o.max_depth, o.device, o.flags = max_depth, device, flags
-        o.stream = stream
+        if stream is not None:      # a caller-owned stream handle; 0 is the legacy default stream (torch's default current stream)
+            o.stream = stream or None
+            o.flags |= FLAG_USE_STREAM
         if rows is not None:
             o.row_begin, o.row_end = rows
         if arena is not None:

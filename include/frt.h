@@ -122,7 +122,7 @@ void frt_camera_default(float aspect, uint32_t frame_count, uint32_t num_lights,
 typedef struct frt_render_opts {
     uint32_t max_depth;       /* MAX_DEPTH, restir.wgsl:5; 0 -> 8 */
     int32_t device;           /* HIP device ordinal */
-    void* stream;             /* hipStream_t to enqueue on; NULL -> a stream owned by the renderer */
+    void* stream;             /* hipStream_t to enqueue on; NULL -> a stream owned by the renderer, unless FRT_FLAG_USE_STREAM */
     uint32_t row_begin;       /* rows [row_begin, row_end) owned by this renderer (image strip); 0,0 -> whole image */
     uint32_t row_end;
     void* device_arena;       /* optional caller-owned device memory for all per-pixel buffers (frt_renderer_arena_bytes) */
@@ -131,6 +131,7 @@ typedef struct frt_render_opts {
     uint32_t reserved;
 } frt_render_opts;
 #define FRT_FLAG_TIMING 1u          /* record per-stage HIP events every frame (frt_stats.ms_*) */
+#define FRT_FLAG_USE_STREAM 4u      /* opts->stream is authoritative even when NULL (= the legacy default stream, e.g. torch's current stream) */
 #define FRT_FLAG_COMPACTION 2u      /* temporal / spatial stages through the workgroup-compacting kernels (opt-in: measured slower than
                                        one thread per pixel on the Cornell Box, profiles/r1_v3_*; same pixels either way) */
 

@@ -5,6 +5,11 @@ import ctypes as C
 import numpy as np
 import pytest
 
+try:                      # load torch's HIP runtime before libfrt.so so that both share one runtime in this process
+    import torch  # noqa: F401
+except Exception:         # torch is only needed by the multi-rank tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fast-raytracing-wgpu_amd"))
 sys.path.insert(0, ROOT)
