@@ -30,6 +30,10 @@ STAGES = ("gbuffer", "temporal", "spatial", "post")
 # Compulsory per-pixel stream bytes of each kernel in this design: G-buffer write 44; temporal read 44+36+32,
 # write 32; spatial read 36+32, write 32+8; post read 68, write 20.
 B_PX = {"gbuffer": 44, "temporal": 144, "spatial": 108, "post": 88}
+# HBM bytes per launch at 1920x1080 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r1_v4_pmc.txt),
+# (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM. Measured offline, not in this run.
+PMC_TRAFFIC_BYTES = {"gbuffer": (2 * 2255 + 89360) * 1024, "temporal": (2 * 128900 + 86890) * 1024,
+                     "spatial": (2 * 159700 + 82890) * 1024, "post": (2 * 226100 + 40630) * 1024}
 
 
 def cpu_share():
@@ -161,7 +165,7 @@ def main():
         # algorithmic bytes of one launch of the dominant kernel: rays * (32 B * nodes/ray + 48 B * tris/ray) + pixels * B_px.
         # nodes/ray and tris/ray are per-ray means on the canonical BVH2 measured by the oracle for that stage (same run at N = 1;
         # the committed figures of DESIGN.md §6 otherwise).
-        defaults = {"gbuffer": (22.9, 4.9), "temporal": (13.9, 7.4), "spatial": (13.5, 7.0), "post": (0.0, 0.0)}
+        defaults = {"gbuffer": (10.1, 1.7), "temporal": (18.8, 2.2), "spatial": (16.5, 2.1), "post": (0.0, 0.0)}
         name = STAGES[dom]
         if per_stage and name in per_stage:
             npr, tpr = per_stage[name]["nodes_per_ray"], per_stage[name]["tris_per_ray"]
@@ -176,8 +180,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell Box 1920x1080, MAX_DEPTH 8, 1 candidate path/pixel/frame, 4-stage ReSTIR-PT frame (BASELINE.json configs[1])",
                        "rays_per_frame": rays / a.steps, "parallelism": "1 GPU" if world == 1 else f"{world} image strips, 1 halo exchange/frame (RCCL)"},
-            "roofline": {"bound": "hbm", "kernel": f"trace_stage_kernel<{dom}> ({name})" if dom < 3 else "post_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": {0: "gbuffer_kernel", 1: "pixel_kernel<1> (temporal)", 2: "pixel_kernel<2> (spatial + shade)", 3: "post_kernel"}[dom], "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(name) if world == 1 else None,
                          "avg_launch_ms": ms[dom], "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_ray": 32.0 * npr + 48.0 * tpr, "rays_per_launch": stage_rays[dom],
                          "note": "scene (91 KB) is L2-resident; HBM sees only the per-pixel streams, so the HBM fraction is small by construction (SURVEY F9)"},
