@@ -1,0 +1,125 @@
+"""Synthetic mesh scenes for BASELINE.json configs[3] / [4], built through the PUBLIC builder calls of both the product
+(frt.SceneBuilder) and the oracle (orc_scene_*), from the same numpy arrays.
+
+The Stanford Bunny and Sponza are not available offline, so stand-ins of comparable size are used:
+  config 3: icosphere(6) (81,920 triangles) displaced radially by a fixed sum of three sinusoids, inside the Cornell walls
+  config 4: a colonnade of 12 x 4 icosphere(4) "capitals" (245,760 triangles) + cube columns in a 10 x 4 x 4 hall, one quad light
+"""
+import ctypes as C
+import numpy as np
+
+
+def _mat(tx, ty, tz, sx, sy, sz):
+    m = np.zeros((4, 4), np.float32)          # column-major: m[c, r]
+    m[0, 0], m[1, 1], m[2, 2], m[3, 3] = sx, sy, sz, 1.0
+    m[3, 0], m[3, 1], m[3, 2] = tx, ty, tz
+    return m.reshape(16)
+
+
+class DualBuilder:
+    """Issues every builder call to both libraries."""
+
+    def __init__(self, frt, orc):
+        self.frt, self.orc = frt, orc
+        self.fb = frt.SceneBuilder()
+        self.oh = orc.L.orc_scene_create()
+
+    def add_mesh(self, pos4, attrs, idx):
+        pos4 = np.ascontiguousarray(pos4, np.float32); attrs = np.ascontiguousarray(attrs, np.float32); idx = np.ascontiguousarray(idx, np.uint32)
+        g = self.frt.geometry.Geometry(pos4, attrs, idx)
+        a = self.fb.add_mesh(g)
+        b = self.orc.L.orc_scene_add_mesh(self.oh, pos4.ctypes.data, pos4.shape[0], attrs.ctypes.data, idx.ctypes.data, idx.size)
+        assert a == b
+        return a
+
+    def add_material(self, mat):
+        a = self.fb.add_material(mat)
+        b = self.orc.L.orc_scene_add_material(self.oh, C.byref(mat))
+        assert a == b
+        return a
+
+    def add_instance(self, mesh, mat, m):
+        m = np.ascontiguousarray(m, np.float32)
+        self.fb.add_instance(mesh, mat, m)
+        self.orc.L.orc_scene_add_instance(self.oh, mesh, mat, m.ctypes.data)
+
+    def add_light(self, light):
+        self.fb.add_light(light)
+        self.orc.L.orc_scene_add_light(self.oh, C.byref(light))
+
+    def build(self):
+        from _oracle import OrcScene
+        self.fb.build()
+        self.orc.L.orc_scene_build(self.oh)
+        osc = OrcScene(self.orc, self.oh)
+        osc.set_bvh(self.fb.get("bvh2_nodes"), self.fb.get("bvh2_tri_index"))
+        return self.fb, osc
+
+
+def _geo(frt, name, *a):
+    g = getattr(frt.geometry, name)(*a)
+    return g.positions.copy(), g.attributes.copy(), g.indices.copy()
+
+
+def _quad_light(frt, pos, half, emission):
+    l = frt.Light()
+    l.position[:] = pos; l.type_ = 0
+    l.u[:] = (half, 0, 0); l.v[:] = (0, 0, half); l.area = 4.0 * half * half
+    l.emission[:] = emission
+    return l
+
+
+def _emissive(frt, light_index, rgb, intensity):
+    m = frt.material_new([1, 1, 1, 1])
+    m.light_index = light_index
+    m.emissive_factor[:] = [c * intensity for c in rgb]
+    m.tex_info_0 = 0xFFFF0000
+    return m
+
+
+def bumpy_sphere_in_box(frt, orc, subdiv=6):
+    """config 3 stand-in. subdiv 6 -> 81,920 triangles (+ 12 wall/light triangles)."""
+    b = DualBuilder(frt, orc)
+    plane = b.add_mesh(*_geo(frt, "create_plane"))
+    pos, att, idx = _geo(frt, "create_sphere", subdiv)
+    p = pos[:, :3].astype(np.float64) * 2.0           # unit directions (radius 0.5 -> 1)
+    disp = 1.0 + 0.08 * np.sin(7.0 * p[:, 0]) * np.sin(5.0 * p[:, 1]) + 0.05 * np.sin(11.0 * p[:, 2] + 1.0) + 0.03 * np.sin(17.0 * p[:, 0] * p[:, 1])
+    pos[:, :3] = (p * disp[:, None] * 0.5).astype(np.float32)
+    blob = b.add_mesh(pos, att, idx)
+    white = b.add_material(frt.material_new([0.73, 0.73, 0.73, 1.0]))
+    red = b.add_material(frt.material_new([0.65, 0.05, 0.05, 1.0]))
+    green = b.add_material(frt.material_new([0.12, 0.45, 0.15, 1.0]))
+    lm = b.add_material(_emissive(frt, 0, (1, 1, 1), 10.0))
+    ref = frt.scenes.create_cornell_box().get("instances")      # reuse the wall transforms of scenes.rs:50-90
+    for k, mat in ((0, white), (1, white), (2, white), (3, red), (4, green)):
+        b.add_instance(plane, mat, ref[k, 5:21].view(np.float32))
+    b.add_instance(plane, lm, ref[5, 5:21].view(np.float32))
+    b.add_light(_quad_light(frt, (0, 0.99, 0), 0.25, (1, 1, 1, 10)))
+    b.add_instance(blob, white, _mat(0, -0.4, 0, 0.6, 0.6, 0.6))
+    return b.build()
+
+
+def colonnade(frt, orc, nx=12, nz=4, subdiv=4):
+    """config 4 stand-in. 12 x 4 x icosphere(4) = 245,760 triangles + columns + hall."""
+    b = DualBuilder(frt, orc)
+    plane = b.add_mesh(*_geo(frt, "create_plane"))
+    cube = b.add_mesh(*_geo(frt, "create_cube"))
+    sph = b.add_mesh(*_geo(frt, "create_sphere", subdiv))
+    stone = b.add_material(frt.material_new([0.7, 0.68, 0.6, 1.0]))
+    floor = frt.material_new([0.73, 0.73, 0.73, 1.0]); floor.roughness = 0.99; floor.tex_info_0 = 0xFFFF0001
+    floor = b.add_material(floor)
+    lm = b.add_material(_emissive(frt, 0, (1, 0.95, 0.85), 30.0))
+    b.add_instance(plane, floor, _mat(0, -1, 0, 10, 1, 4))
+    ceil = _mat(0, 1.0, 0, 10, 1, 4); ceil[5] = -1.0; ceil[10] = -4.0        # flip about x: normal down
+    b.add_instance(plane, stone, ceil)
+    lq = _mat(0, 0.98, 0, 2.0, 1, 1.0); lq[5] = -1.0; lq[10] = -1.0
+    b.add_instance(plane, lm, lq)
+    l = _quad_light(frt, (0, 0.98, 0), 0.5, (1, 0.95, 0.85, 30)); l.u[:] = (1.0, 0, 0); l.v[:] = (0, 0, 0.5); l.area = 2.0
+    b.add_light(l)
+    for i in range(nx):
+        for k in range(nz):
+            x = (i - (nx - 1) / 2) * 0.8
+            z = (k - (nz - 1) / 2) * 0.9
+            b.add_instance(cube, stone, _mat(x, -0.35, z, 0.18, 1.3, 0.18))
+            b.add_instance(sph, stone, _mat(x, 0.42, z, 0.45, 0.3, 0.45))
+    return b.build()
