@@ -7,6 +7,7 @@
 // Boxes are padded so that box tests are strictly more permissive than the ray/triangle test (hit semantics do not
 // depend on the tree: DESIGN.md §3).
 #include "frt_scene.hpp"
+#include "frt_shade.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -143,7 +144,7 @@ void SceneBuilder::build_bvh2() {
 }
 
 void SceneBuilder::build_gpu_layout() {
-    pair_nodes.clear(); tri_slots.clear(); instances_dev.clear();
+    pair_nodes.clear(); tri_slots.clear(); instances_dev.clear(); shade_tris.clear();
     if (!error.empty()) return;
     // triangle slots in leaf (bvh2_tri_index) order
     tri_slots.resize(tris.size());
@@ -199,6 +200,25 @@ void SceneBuilder::build_gpu_layout() {
             for (int c = 0; c < 2; ++c) { put_box(p, c, &bvh2[n.left_first + c]); put_ref(p, c, ref_of(n.left_first + c)); }
             pair_nodes[i] = p;
         }
+    }
+    // shading records: the instance -> mesh -> index -> attribute chain of gbuffer.wgsl:129-145, flattened per triangle
+    shade_tris.assign(tris.size(), ShadeTri{});
+    for (size_t id = 0; id < tris.size(); ++id) {
+        const InstanceRec& in = instances[tri_instance[id]];
+        const MeshInfo& mi = mesh_infos[in.mesh_id];
+        uint32_t prim = (uint32_t)id - in.first_tri;
+        ShadeTri& o = shade_tris[id];
+        for (int k = 0; k < 3; ++k) {
+            const frt_vertex_attr& a = attributes[indices[mi.index_offset + prim * 3u + k] + mi.vertex_offset];
+            f3 n = decode_octahedral_normal(a.normal[0], a.normal[1]);   // same function the kernels would run per hit
+            o.q[4 * k] = n.x; o.q[4 * k + 1] = n.y; o.q[4 * k + 2] = n.z;
+            o.q[12 + 4 * k] = a.tangent[0]; o.q[12 + 4 * k + 1] = a.tangent[1]; o.q[12 + 4 * k + 2] = a.tangent[2];
+            // uvs: (uv0.x, uv0.y, uv1.x, uv1.y, uv2.x, uv2.y) in the .w lanes of q0..q5
+            o.q[4 * (2 * k) + 3] = a.uv[0]; o.q[4 * (2 * k + 1) + 3] = a.uv[1];
+            if (k == 0) o.q[24] = a.tangent[3];
+        }
+        uint32_t mat = in.mat_id;
+        memcpy(&o.q[25], &mat, 4);
     }
     instances_dev.resize(instances.size());
     for (size_t i = 0; i < instances.size(); ++i) {

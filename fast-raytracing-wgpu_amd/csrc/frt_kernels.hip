@@ -208,19 +208,88 @@ __global__ void __launch_bounds__(kBlockC) compact_kernel(SceneView sc, FrameVie
     flush_ray_counters(fv, n_closest, n_any, s_cnt);
 }
 
-// Default temporal / spatial kernels: one thread per pixel, straight-line trace_path (frt_mono.hpp). Fastest measured form.
+// Default temporal (STAGE 1) / spatial + shade (STAGE 2) kernels: one thread per pixel runs the primary hit and the bounces
+// below `cut` (frt_mono.hpp). 83 % of the rays of a Cornell frame are fired at depth <= 2, but almost every 8x8 tile has a lane
+// that survives to depth 5-7, so an uncut wave spends most of its bounce iterations with a handful of live lanes (24 % lane
+// utilisation, profiles/r1_v4_pmc.txt). Paths still alive at `cut` are therefore PARKED: a wave ballot finds them, the leader
+// reserves popcount(ballot) slots of a continuation queue in HBM with one atomic, every survivor writes its 22-30 words of
+// loop state at slot base + rank (SoA, so the wave writes full rows), and the lane retires. continue_kernel then resumes the
+// parked paths one per lane — dense waves again — and may park its own survivors for a further launch. Pixels are unchanged:
+// a path's arithmetic and rand() sequence do not depend on the lane or launch that runs it.
+__device__ __forceinline__ uint32_t wave_reserve(uint32_t* count, bool want) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return 0u;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0u;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 template <int STAGE>
-__global__ void __launch_bounds__(kBlock) pixel_kernel(SceneView sc, FrameView fv) {
+__device__ __forceinline__ void finish_path(PathCtx& c, uint32_t pix, const ReservoirView& r, const LoopState& s) {
+    if (STAGE == 1) { PathState st; make_path_state(st, pix, s.accumulated, s.v1_pos); temporal_finalize(c, st); }
+    else spatial_tail(c, pix, r, s.accumulated, s.v1_pos);
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut) {
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     __shared__ uint32_t s_cnt[2];
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
+    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
     uint32_t px, py;
-    bool active = tile_pixel(fv, px, py);
+    const bool active = tile_pixel(fv, px, py);
     PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
-    if (active) { if (STAGE == 1) temporal_pixel(c, px, py); else spatial_pixel(c, px, py); }
-    bool counted = active && py >= fv.own_y0 && py < fv.own_y1;
+    const uint32_t pix = py * fv.W + px;
+    const bool counted = active && py >= fv.own_y0 && py < fv.own_y1;
+    LoopState s;
+    s.alive = false;
+    ReservoirView r = zero_reservoir();
+    bool traced = false;
+    if (active) {
+        uint32_t seed = 0u;
+        if (STAGE == 1) {
+            if (fv.gpos[pix].w < 0.0f) fv.res_temporal[pix] = zero_reservoir();   // restir.wgsl:805-811
+            else { seed = temporal_seed(fv, pix); traced = true; }
+        } else if (spatial_neighbors(c, pix, r)) { seed = r.y; traced = true; }
+        if (traced) {
+            path_head<VARIANT>(c, pix, seed, s);
+            if (s.alive) path_loop<VARIANT>(c, s, 1u, cut < fv.max_depth ? cut : fv.max_depth);
+            if (!s.alive) finish_path<STAGE>(c, pix, r, s);
+        }
+    }
+    const uint32_t slot = wave_reserve(q.count, s.alive);
+    if (s.alive) cont_store(q, slot, pix, c.rng, counted, s, STAGE == 2 ? &r : nullptr);
     flush_ray_counters(fv, counted ? c.n_closest : 0u, counted ? c.n_any : 0u, s_cnt);
+}
+
+// Resumes parked paths for bounces [d0, d1); survivors are parked again in `qout` (d1 < MAX_DEPTH) or finished here.
+template <int STAGE>
+__global__ void __launch_bounds__(kBlock, 4) continue_kernel(SceneView sc, FrameView fv, ContQueue qin, ContQueue qout, uint32_t d0, uint32_t d1) {
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    __shared__ uint32_t s_cnt[2];
+    const uint32_t n = *qin.count;
+    if (blockIdx.x * (uint32_t)kBlock >= n) return;   // uniform per workgroup: the grid is sized for the worst case
+    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
+    const uint32_t slot_in = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
+    LoopState s;
+    s.alive = false;
+    ReservoirView r = zero_reservoir();
+    uint32_t pix = 0u;
+    bool owned = false;
+    if (slot_in < n) {
+        cont_load(qin, slot_in, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+        path_loop<VARIANT>(c, s, d0, d1);
+        if (!s.alive) finish_path<STAGE>(c, pix, r, s);
+    }
+    const uint32_t slot = wave_reserve(qout.count, s.alive);
+    if (s.alive) cont_store(qout, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+    flush_ray_counters(fv, owned ? c.n_closest : 0u, owned ? c.n_any : 0u, s_cnt);
 }
 
 __global__ void __launch_bounds__(kBlock) post_kernel(FrameView fv) {
@@ -230,22 +299,30 @@ __global__ void __launch_bounds__(kBlock) post_kernel(FrameView fv) {
 
 static dim3 grid_for(const FrameView& fv) { return dim3((fv.W + 15u) / 16u, (fv.y1 - fv.y0 + 15u) / 16u, 1u); }
 
-hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, bool compaction) {
+hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const StageLaunch& L) {
     if (fv.y1 <= fv.y0 || fv.W == 0u) return hipSuccess;
     dim3 grid = grid_for(fv), block(kBlock);
-    dim3 cgrid((fv.W + 31u) / 32u, (fv.y1 - fv.y0 + 15u) / 16u, 1u), cblock(kBlockC);
-    switch (stage) {
-    case 0: hipLaunchKernelGGL(gbuffer_kernel, grid, block, 0, stream, sc, fv); break;
-    case 1:
-        if (compaction) hipLaunchKernelGGL(compact_kernel<1>, cgrid, cblock, 0, stream, sc, fv);
-        else hipLaunchKernelGGL(pixel_kernel<1>, grid, block, 0, stream, sc, fv);
-        break;
-    case 2:
-        if (compaction) hipLaunchKernelGGL(compact_kernel<2>, cgrid, cblock, 0, stream, sc, fv);
-        else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv);
-        break;
-    case 3: hipLaunchKernelGGL(post_kernel, grid, block, 0, stream, fv); break;
-    default: return hipErrorInvalidValue;
+    if (stage == 0) hipLaunchKernelGGL(gbuffer_kernel, grid, block, 0, stream, sc, fv);
+    else if (stage == 3) hipLaunchKernelGGL(post_kernel, grid, block, 0, stream, fv);
+    else if (stage != 1 && stage != 2) return hipErrorInvalidValue;
+    else if (L.compaction) {
+        dim3 cgrid((fv.W + 31u) / 32u, (fv.y1 - fv.y0 + 15u) / 16u, 1u), cblock(kBlockC);
+        if (stage == 1) hipLaunchKernelGGL(compact_kernel<1>, cgrid, cblock, 0, stream, sc, fv);
+        else hipLaunchKernelGGL(compact_kernel<2>, cgrid, cblock, 0, stream, sc, fv);
+    } else {
+        // pixel kernel up to the first cut, then one continuation launch per further segment, ping-ponging the two queues
+        const ContQueue* q = L.queues;   // [0], [1]
+        uint32_t first = L.ncuts ? L.cuts[0] : fv.max_depth;
+        if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, block, 0, stream, sc, fv, q[0], first);
+        else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv, q[0], first);
+        dim3 qgrid((q[0].capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
+        int in = 0;
+        for (uint32_t k = 0; k < L.ncuts && L.cuts[k] < fv.max_depth; ++k) {
+            uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
+            if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, qgrid, block, 0, stream, sc, fv, q[in], q[in ^ 1], d0, d1);
+            else hipLaunchKernelGGL(continue_kernel<2>, qgrid, block, 0, stream, sc, fv, q[in], q[in ^ 1], d0, d1);
+            in ^= 1;
+        }
     }
     return hipGetLastError();
 }

@@ -38,7 +38,8 @@ FRT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 FRT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 FRT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 FRT_HD f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
-FRT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+// vector / scalar: one IEEE reciprocal, then three multiplies (contract; WGSL allows 2.5 ulp for division)
+FRT_HD f3 operator/(f3 a, float s) { float r = 1.0f / s; return mk3(a.x * r, a.y * r, a.z * r); }
 FRT_HD f3 operator-(float s, f3 a) { return mk3(s - a.x, s - a.y, s - a.z); }
 FRT_HD f4 operator+(f4 a, f4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 FRT_HD f4 operator*(f4 a, float s) { return mk4(a.x * s, a.y * s, a.z * s, a.w * s); }
@@ -142,6 +143,10 @@ FRT_HD float log2f_(float x) {
     r = r + m;
     return r + (float)e;
 }
+// pow(x, 5) and pow(x, 20) of the shaders (Schlick terms restir.wgsl:171, :179; normal weight post.wgsl:125) by repeated
+// multiplication, x >= 0 at every call site
+FRT_HD float pow5_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x; }
+FRT_HD float pow20_(float x) { float x2 = x * x; float x4 = x2 * x2; float x8 = x4 * x4; float x16 = x8 * x8; return x16 * x4; }
 FRT_HD float powf_(float x, float y) { return (x > 0.0f) ? exp2f_(y * log2f_(x)) : 0.0f; }
 FRT_HD float expf_(float x) { return exp2f_(x * 1.44269504088896340736f); }
 

@@ -55,16 +55,25 @@ FRT_HD f3 nee(PathCtx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_co
     return splat3(0.0f);
 }
 
-struct PathOut { f3 radiance; f3 v1_pos; };
+// State of a path at the top of the bounce loop (restir.wgsl:590): everything an iteration reads that earlier code wrote.
+// A path can be cut here, parked in HBM (frt_kernels.hip: continuation queue) and resumed by another lane.
+struct LoopState {
+    f3 pos, ffnormal, throughput, accumulated, next_dir, v1_pos;
+    float last_bsdf_pdf;
+    bool previous_was_diffuse, is_glass, alive;
+};
 
-// restir.wgsl:460-737 (VARIANT 0) / restir_spatial.wgsl:480-762 (VARIANT 1)
+// restir.wgsl:460-584 (VARIANT 0) / restir_spatial.wgsl:480-610 (VARIANT 1): the primary hit, read from the G-buffer.
+// Returns with s.alive == false when the path ended here (background, light surface, zero BSDF weight).
 template <int VARIANT>
-FRT_HD PathOut trace_path(PathCtx& c, uint32_t pix, uint32_t seed) {
+FRT_HD void path_head(PathCtx& c, uint32_t pix, uint32_t seed, LoopState& s) {
     const SceneView& sc = c.sc; const FrameView& fv = c.fv;
     c.rng = seed;
-    PathOut out; out.radiance = splat3(0.0f); out.v1_pos = splat3(0.0f);
+    s.accumulated = splat3(0.0f); s.v1_pos = splat3(0.0f); s.throughput = splat3(1.0f); s.next_dir = splat3(0.0f);
+    s.pos = splat3(0.0f); s.ffnormal = splat3(0.0f); s.last_bsdf_pdf = 0.0f;
+    s.previous_was_diffuse = false; s.is_glass = false; s.alive = false;
     float4 pos_w = fv.gpos[pix];
-    if (pos_w.w < 0.0f) return out;
+    if (pos_w.w < 0.0f) return;
     float4 normal_w = fv.gnormal[pix];
     f4 albedo_raw = unpack_rgba8(fv.galbedo[pix]);
 
@@ -110,8 +119,8 @@ FRT_HD PathOut trace_path(PathCtx& c, uint32_t pix, uint32_t seed) {
         f3 emission = emissive_factor;
         if (emissive_tex_id != 65535u) emission = emission * xyz(sample_layer<true>(sc, emissive_tex_id, hit.uv));
         accumulated = accumulated + emission;
-        out.radiance = accumulated;
-        return out;
+        s.accumulated = accumulated;
+        return;
     }
     const bool is_glass = m.transmission > 0.01f;
     bool previous_was_diffuse;
@@ -121,12 +130,31 @@ FRT_HD PathOut trace_path(PathCtx& c, uint32_t pix, uint32_t seed) {
     } else previous_was_diffuse = false;
 
     BsdfSmp sc0 = sample_bsdf(c, wo, hit.ffnormal, hit.front_face, m, base_color);
-    if (sc0.weight.x <= 0.0f && sc0.weight.y <= 0.0f && sc0.weight.z <= 0.0f) { out.radiance = accumulated; return out; }
-    float last_bsdf_pdf = sc0.pdf;
-    throughput = throughput * sc0.weight;
-    f3 next_dir = sc0.wi;
+    s.accumulated = accumulated;
+    if (sc0.weight.x <= 0.0f && sc0.weight.y <= 0.0f && sc0.weight.z <= 0.0f) return;
+    s.last_bsdf_pdf = sc0.pdf;
+    s.throughput = throughput * sc0.weight;
+    s.next_dir = sc0.wi;
+    s.pos = hit.pos; s.ffnormal = hit.ffnormal;
+    s.previous_was_diffuse = previous_was_diffuse; s.is_glass = is_glass;
+    s.alive = true;
+}
 
-    for (uint32_t depth = 1u; depth < fv.max_depth; depth++) {   // :590
+// Bounce loop, iterations depth_begin .. depth_end-1 of `for (depth = 1; depth < MAX_DEPTH; depth++)` (restir.wgsl:590-733).
+// On return s.alive tells whether the path is still running (it reached depth_end without terminating).
+template <int VARIANT>
+FRT_HD void path_loop(PathCtx& c, LoopState& s, uint32_t depth_begin, uint32_t depth_end) {
+    const SceneView& sc = c.sc; const FrameView& fv = c.fv;
+    Surf hit;
+    hit.pos = s.pos; hit.ffnormal = s.ffnormal; hit.normal = s.ffnormal; hit.front_face = true;
+    hit.uv = mk2(0.0f, 0.0f); hit.t = 0.0f; hit.tangent = mk4(0, 0, 0, 0); hit.mat_id = 0u;
+    f3 accumulated = s.accumulated, throughput = s.throughput, next_dir = s.next_dir;
+    float last_bsdf_pdf = s.last_bsdf_pdf;
+    bool previous_was_diffuse = s.previous_was_diffuse;
+    const bool is_glass = s.is_glass;
+    bool alive = true;
+    for (uint32_t depth = depth_begin; depth < depth_end; depth++) {
+        alive = false;
         if (depth >= 3u) {
             float p = fmaxn(throughput.x, fmaxn(throughput.y, throughput.z));
             float survival_prob = clampf(p, 0.05f, 0.95f);
@@ -141,16 +169,16 @@ FRT_HD PathOut trace_path(PathCtx& c, uint32_t pix, uint32_t seed) {
         if (h.tri == 0xFFFFFFFFu) break;
         HitGeom g = fetch_hit_geometry(sc, h);   // reconstruct_geometry_hit, :383-441
         hit.normal = g.normal_w;
-        hit.tangent = mk4(g.tangent_w, g.tangent_sign);
         hit.uv = g.uv;
         hit.front_face = h.front;
         hit.ffnormal = h.front ? g.normal_w : -g.normal_w;
         hit.t = h.t;
         hit.pos = origin + next_dir * h.t;
         hit.mat_id = g.mat_id;
-        if (depth == 1u) out.v1_pos = hit.pos;
-        wo = -next_dir;
+        if (depth == 1u) s.v1_pos = hit.pos;
+        f3 wo = -next_dir;
         const MaterialView& mb = sc.materials[hit.mat_id];
+        MatParams m;
         m.roughness = mb.roughness; m.metallic = mb.metallic; m.transmission = mb.transmission; m.ior = mb.ior;
         int32_t light_index_b = mb.light_index;
         uint32_t t0i = mb.tex_info_0, t1i = mb.tex_info_1;
@@ -160,10 +188,11 @@ FRT_HD PathOut trace_path(PathCtx& c, uint32_t pix, uint32_t seed) {
         float occlusion = 1.0f;
         uint32_t occlusion_tex_id = t1i & 0xFFFFu, emissive_tex_id_b = t1i >> 16u;
         if (occlusion_tex_id != 65535u) occlusion = sample_layer<false>(sc, occlusion_tex_id, hit.uv).x;
-        base_color = mk3(mb.base_color[0], mb.base_color[1], mb.base_color[2]) * xyz(tex_color) * occlusion;
+        f3 base_color = mk3(mb.base_color[0], mb.base_color[1], mb.base_color[2]) * xyz(tex_color) * occlusion;
         if (normal_tex_id != 65535u) {
             f3 nm = xyz(sample_layer<false>(sc, normal_tex_id, hit.uv));
-            hit.ffnormal = perturb_normal(hit.ffnormal, xyz(hit.tangent), hit.tangent.w, nm);
+            f4 tg = hit_tangent(sc, g);
+            hit.ffnormal = perturb_normal(hit.ffnormal, xyz(tg), tg.w, nm);
         }
         if (light_index_b == -1 && emissive_tex_id_b != 65535u) {   // :675-678
             f3 emissive_col = xyz(sample_layer<true>(sc, emissive_tex_id_b, hit.uv));
@@ -195,147 +224,111 @@ FRT_HD PathOut trace_path(PathCtx& c, uint32_t pix, uint32_t seed) {
         last_bsdf_pdf = sb.pdf;
         throughput = throughput * sb.weight;
         next_dir = sb.wi;
+        alive = true;
     }
-    out.radiance = accumulated;
+    s.pos = hit.pos; s.ffnormal = hit.ffnormal; s.accumulated = accumulated; s.throughput = throughput; s.next_dir = next_dir;
+    s.last_bsdf_pdf = last_bsdf_pdf; s.previous_was_diffuse = previous_was_diffuse;
+    s.alive = alive && depth_end < fv.max_depth;
+}
+
+// ---- continuation records: a LoopState parked in HBM between two launches -------------------------------------------------
+// SoA over slots: word k of slot i lives at words[k * capacity + i], so a wave parking / fetching consecutive slots moves full
+// 256-byte rows per word. 22 words (88 B) per path; the spatial stage adds its merged reservoir (8 words).
+struct ContQueue { uint32_t* words; uint32_t* count; uint32_t capacity; };
+static constexpr int kContWordsPath = 22, kContWordsSpatial = 30;
+
+FRT_HD void cont_store(const ContQueue& q, uint32_t slot, uint32_t pix, uint32_t rng, bool owned, const LoopState& s, const ReservoirView* r) {
+    uint32_t* w = q.words + slot;
+    const size_t cap = q.capacity;
+    w[0 * cap] = pix; w[1 * cap] = rng;
+    w[2 * cap] = (s.previous_was_diffuse ? 1u : 0u) | (s.is_glass ? 2u : 0u) | (owned ? 4u : 0u);
+    const float f[19] = {s.pos.x, s.pos.y, s.pos.z, s.ffnormal.x, s.ffnormal.y, s.ffnormal.z, s.throughput.x, s.throughput.y, s.throughput.z,
+                         s.accumulated.x, s.accumulated.y, s.accumulated.z, s.next_dir.x, s.next_dir.y, s.next_dir.z,
+                         s.v1_pos.x, s.v1_pos.y, s.v1_pos.z, s.last_bsdf_pdf};
+#pragma unroll
+    for (int k = 0; k < 19; ++k) w[(size_t)(3 + k) * cap] = f2u(f[k]);
+    if (r) {
+        w[22 * cap] = r->y; w[23 * cap] = f2u(r->w_sum); w[24 * cap] = r->M; w[25 * cap] = f2u(r->W);
+        w[26 * cap] = f2u(r->sx); w[27 * cap] = f2u(r->sy); w[28 * cap] = f2u(r->sz); w[29 * cap] = f2u(r->p_hat);
+    }
+}
+FRT_HD void cont_load(const ContQueue& q, uint32_t slot, uint32_t& pix, uint32_t& rng, bool& owned, LoopState& s, ReservoirView* r) {
+    const uint32_t* w = q.words + slot;
+    const size_t cap = q.capacity;
+    pix = w[0 * cap]; rng = w[1 * cap];
+    uint32_t fl = w[2 * cap];
+    s.previous_was_diffuse = fl & 1u; s.is_glass = fl & 2u; owned = fl & 4u;
+    float f[19];
+#pragma unroll
+    for (int k = 0; k < 19; ++k) f[k] = u2f(w[(size_t)(3 + k) * cap]);
+    s.pos = mk3(f[0], f[1], f[2]); s.ffnormal = mk3(f[3], f[4], f[5]); s.throughput = mk3(f[6], f[7], f[8]);
+    s.accumulated = mk3(f[9], f[10], f[11]); s.next_dir = mk3(f[12], f[13], f[14]); s.v1_pos = mk3(f[15], f[16], f[17]);
+    s.last_bsdf_pdf = f[18];
+    s.alive = true;
+    if (r) {
+        r->y = w[22 * cap]; r->w_sum = u2f(w[23 * cap]); r->M = w[24 * cap]; r->W = u2f(w[25 * cap]);
+        r->sx = u2f(w[26 * cap]); r->sy = u2f(w[27 * cap]); r->sz = u2f(w[28 * cap]); r->p_hat = u2f(w[29 * cap]);
+    }
+}
+
+struct PathOut { f3 radiance; f3 v1_pos; };
+
+// restir.wgsl:460-737 (VARIANT 0) / restir_spatial.wgsl:480-762 (VARIANT 1), uncut.
+template <int VARIANT>
+FRT_HD PathOut trace_path(PathCtx& c, uint32_t pix, uint32_t seed) {
+    LoopState s;
+    path_head<VARIANT>(c, pix, seed, s);
+    if (s.alive) path_loop<VARIANT>(c, s, 1u, c.fv.max_depth);
+    PathOut out; out.radiance = s.accumulated; out.v1_pos = s.v1_pos;
     return out;
 }
 
-// ================================================================================================ stage 1: restir.wgsl:788-918
+// ---- stage bodies, split at trace_path so that a path can be finished by another lane -------------------------------------
+FRT_HD void make_path_state(PathState& st, uint32_t pix, f3 radiance, f3 v1_pos) { st.pix = pix; st.accum = radiance; st.v1_pos = v1_pos; }
+
+// temporal: restir.wgsl:788-918. begin -> [trace_path] -> temporal_finalize (frt_path.hpp)
 FRT_HD void temporal_pixel(PathCtx& c, uint32_t px, uint32_t py) {
-    const SceneView& sc = c.sc; const FrameView& fv = c.fv;
-    uint32_t pixel_idx = px + py * fv.W;
-    uint32_t seed_base = pixel_idx + fv.cam.frame_count * 927163u;
-    uint32_t seed_candidate = pcg_hash(seed_base);
-    uint32_t local_seed = seed_base;
-    float4 pos_w = fv.gpos[pixel_idx];
-    if (pos_w.w < 0.0f) { fv.res_temporal[pixel_idx] = zero_reservoir(); return; }
-    ReservoirView r = zero_reservoir();
-    PathOut path = trace_path<0>(c, pixel_idx, seed_candidate);
-    float p_hat = luminance(path.radiance);
-    update_reservoir(r, seed_candidate, p_hat, 0.5f, 1u, p_hat, path.v1_pos);
-    r.W = p_hat > 0.0f ? 1.0f : 0.0f;
-
-    float2 motion = fv.gmotion[pixel_idx];
-    f2 size = mk2((float)fv.W, (float)fv.H);
-    f2 uv = (mk2((float)px, (float)py) + mk2(0.5f, 0.5f)) / size;
-    f2 prev_uv = uv + mk2(motion.x, motion.y);
-    if (prev_uv.x >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y >= 0.0f && prev_uv.y <= 1.0f) {
-        f2 pf = prev_uv * size;
-        uint32_t qx = (uint32_t)pf.x, qy = (uint32_t)pf.y;
-        bool inb = qx < fv.W && qy < fv.H;          // prev_uv == 1.0: out-of-range texel reads give zeros
-        uint32_t prev_idx = inb ? qy * fv.W + qx : 0u;
-        float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float4 prev_pos = inb ? fv.gpos_prev[prev_idx] : zero4;
-        float4 prev_nrm = inb ? fv.gnormal_prev[prev_idx] : zero4;
-        f3 prev_normal = decode_octahedral_normal(prev_nrm.x, prev_nrm.y);
-        uint32_t prev_mat_id = (uint32_t)(prev_pos.w + 0.1f);
-        float4 cur_nrm = fv.gnormal[pixel_idx];
-        f3 curr_normal = decode_octahedral_normal(cur_nrm.x, cur_nrm.y);
-        uint32_t curr_mat_id = (uint32_t)(pos_w.w + 0.1f);
-        const MaterialView& mat = sc.materials[curr_mat_id];
-        bool is_specular = mat.roughness < 0.2f || mat.metallic > 0.8f || (mat.transmission > 0.01f);
-        f3 cam = mk3(fv.cam.view_pos[0], fv.cam.view_pos[1], fv.cam.view_pos[2]);
-        if (is_valid_neighbor_temporal(mk3(pos_w.x, pos_w.y, pos_w.z), curr_normal, curr_mat_id,
-                                       mk3(prev_pos.x, prev_pos.y, prev_pos.z), prev_normal, prev_mat_id, cam) && !is_specular) {
-            ReservoirView prev_r = inb ? fv.res_spatial[prev_idx] : zero_reservoir();
-            f3 curr_albedo = xyz(unpack_rgba8(fv.galbedo[pixel_idx]));
-            f3 prev_albedo = inb ? xyz(unpack_rgba8(fv.galbedo_prev[prev_idx])) : splat3(0.0f);
-            float l_curr = luminance(curr_albedo) + 0.001f;
-            float l_prev = luminance(prev_albedo) + 0.001f;
-            float albedo_ratio = l_curr / l_prev;
-            if (albedo_ratio < 3.0f && albedo_ratio > 0.33f) {
-                float p_hat_new = prev_r.p_hat * albedo_ratio;
-                if (p_hat_new > 0.0f) {
-                    uint32_t clamped_M = prev_r.M < 16u ? prev_r.M : 16u;   // MAX_RESERVOIR_M_TEMPORAL, :851
-                    float w_prev = p_hat_new * prev_r.W * (float)clamped_M;
-                    update_reservoir(r, prev_r.y, w_prev, rand_lcg(local_seed), clamped_M, p_hat_new, mk3(prev_r.sx, prev_r.sy, prev_r.sz));
-                }
-            }
-        }
-    }
-    float p_hat_final = r.p_hat;
-    if (p_hat_final > 0.0f) r.W = (1.0f / p_hat_final) * (r.w_sum / (float)r.M);
-    else { r.W = 0.0f; r.p_hat = 0.0f; }
-    fv.res_temporal[pixel_idx] = r;
+    const uint32_t pix = px + py * c.fv.W;
+    if (c.fv.gpos[pix].w < 0.0f) { c.fv.res_temporal[pix] = zero_reservoir(); return; }   // :805-811
+    PathOut path = trace_path<0>(c, pix, temporal_seed(c.fv, pix));
+    PathState st;
+    make_path_state(st, pix, path.radiance, path.v1_pos);
+    temporal_finalize(c, st);
 }
 
-// ================================================================================================ stage 2: restir_spatial.wgsl:857-1016
+// spatial: restir_spatial.wgsl:857-1016. Neighbour loop (:912-993) -> merged reservoir r; [trace_path(r.y)] -> spatial_finalize.
+// false: background pixel (outputs written).
+FRT_HD bool spatial_neighbors(PathCtx& c, uint32_t pix, ReservoirView& r) {
+    SpatialState ss;
+    if (!spatial_begin(c, ss, pix)) return false;
+    while (ss.i < ss.n) {
+        AnyReq req;
+        req.want = false; req.o = splat3(0.0f); req.d = splat3(0.0f); req.tmin = 0.0f; req.tmax = 0.0f;
+        spatial_neighbor_prepare(c, ss, req);
+        bool visible = true;
+        if (req.want) {
+            HitRec h;
+            c.n_any++;
+            trace<true>(c.sc, req.o, req.d, req.tmin, req.tmax, c.stk, c.stride, h);
+            visible = h.tri == 0xFFFFFFFFu;
+        }
+        spatial_neighbor_finish(ss, visible);
+    }
+    r = ss.r;
+    return true;
+}
+FRT_HD void spatial_tail(PathCtx& c, uint32_t pix, const ReservoirView& r, f3 radiance, f3 v1_pos) {
+    SpatialState ss; ss.r = r; ss.pix = pix;
+    PathState st;
+    make_path_state(st, pix, radiance, v1_pos);
+    spatial_finalize(c, ss, st);
+}
 FRT_HD void spatial_pixel(PathCtx& c, uint32_t px, uint32_t py) {
-    const SceneView& sc = c.sc; const FrameView& fv = c.fv;
-    uint32_t pixel_idx = py * fv.W + px;
-    uint32_t seed_init = py * fv.W + px + fv.frame_count * 0x12345678u;   // scene_info.y (restir_spatial.rs execute)
-    uint32_t local_seed = seed_init;
-    float4 pos_w4 = fv.gpos[pixel_idx];
-    if (pos_w4.w < 0.0f) {
-        fv.res_spatial[pixel_idx] = zero_reservoir();
-        fv.raw[pixel_idx] = pack_rgba16f(mk4(0.0f, 0.0f, 0.0f, 0.0f));
-        return;
-    }
-    f3 pos_w = mk3(pos_w4.x, pos_w4.y, pos_w4.z);
-    float4 normal_w = fv.gnormal[pixel_idx];
-    f3 normal = decode_octahedral_normal(normal_w.x, normal_w.y);
-    uint32_t mat_id = (uint32_t)(pos_w4.w + 0.1f);
-    f3 albedo = xyz(unpack_rgba8(fv.galbedo[pixel_idx]));
-    ReservoirView r = fv.res_temporal[pixel_idx];
-    if (r.M > 20u) { r.w_sum *= 20.0f / (float)r.M; r.M = 20u; }
-    f3 camera_pos = mk3(fv.cam.view_pos[0], fv.cam.view_pos[1], fv.cam.view_pos[2]);
-    const MaterialView& mat = sc.materials[mat_id];
-    const bool narrow = mat.roughness < 0.1f || mat.metallic > 0.9f || mat.transmission > 0.1f;   // :906 and :957
-    uint32_t num_neighbors = narrow ? 3u : 5u;
-    float radius = narrow ? 4.0f : 10.0f;
-    for (uint32_t i = 0u; i < num_neighbors; i++) {
-        float r1 = rand_lcg(local_seed);
-        float r2 = rand_lcg(local_seed);
-        float angle = 2.0f * kPI * r1;
-        float rad = sqrtf_(r2) * radius;
-        float sa, ca;
-        sincosf_(angle, sa, ca);
-        f2 offset = mk2(ca, sa) * rad;
-        int nx = (int)px + (int)offset.x, ny = (int)py + (int)offset.y;   // vec2<i32>(offset) truncates toward zero
-        if (nx < 0 || nx >= (int)fv.W || ny < 0 || ny >= (int)fv.H) continue;
-        uint32_t nidx = (uint32_t)ny * fv.W + (uint32_t)nx;
-        float4 n_pos4 = fv.gpos[nidx];
-        if (n_pos4.w < 0.0f) continue;
-        f3 n_pos = mk3(n_pos4.x, n_pos4.y, n_pos4.z);
-        float4 n_nrm = fv.gnormal[nidx];
-        f3 n_normal = decode_octahedral_normal(n_nrm.x, n_nrm.y);
-        uint32_t n_mat_id = (uint32_t)(n_pos4.w + 0.1f);
-        f3 n_albedo = xyz(unpack_rgba8(fv.galbedo[nidx]));
-        if (!is_valid_neighbor_spatial(sc, pos_w, normal, mat_id, n_pos, n_normal, n_mat_id, camera_pos)) continue;
-        ReservoirView nr = fv.res_temporal[nidx];
-        if (nr.p_hat <= 0.0f) continue;
-        f3 n_s_path = mk3(nr.sx, nr.sy, nr.sz);
-        float jacobian = calculate_jacobian(pos_w, normal, albedo, n_s_path, n_pos, n_normal, n_albedo);
-        if (narrow) { if (jacobian < 0.5f || jacobian > 2.0f) continue; }
-        f3 dir_to_v1 = n_s_path - pos_w;
-        float dist_to_v1 = length(dir_to_v1);
-        bool visible = false;
-        if (dot(normal, dir_to_v1) > 0.0f) {
-            if (dist_to_v1 > 0.001f) {
-                f3 ray_dir = normalize(dir_to_v1);
-                float t_max = fmaxn(dist_to_v1, 0.0f);
-                if (trace_shadow_ray<1>(c, pos_w, ray_dir, t_max)) visible = true;
-            }
-        }
-        if (!visible) continue;
-        float p_hat_corrected = nr.p_hat * jacobian;
-        uint32_t M_new = nr.M < 20u ? nr.M : 20u;
-        float weight = p_hat_corrected * nr.W * (float)M_new;
-        update_reservoir(r, nr.y, weight, rand_lcg(local_seed), M_new, p_hat_corrected, n_s_path);
-    }
-    PathOut fin = trace_path<1>(c, pixel_idx, r.y);
-    f3 final_color = splat3(0.0f);
-    float p_hat_final = luminance(fin.radiance);
-    r.sx = fin.v1_pos.x; r.sy = fin.v1_pos.y; r.sz = fin.v1_pos.z;
-    if (p_hat_final > 0.0f) {
-        float w_unclamped = (1.0f / p_hat_final) * (r.w_sum / (float)r.M);
-        r.W = clampf(w_unclamped, 0.0f, 20.0f);
-        final_color = fin.radiance * r.W;
-        r.p_hat = p_hat_final;
-    } else { r.W = 0.0f; r.p_hat = 0.0f; }
-    fv.res_spatial[pixel_idx] = r;
-    fv.raw[pixel_idx] = pack_rgba16f(mk4(final_color, 1.0f));
+    const uint32_t pix = py * c.fv.W + px;
+    ReservoirView r;
+    if (!spatial_neighbors(c, pix, r)) return;
+    PathOut fin = trace_path<1>(c, pix, r.y);
+    spatial_tail(c, pix, r, fin.radiance, fin.v1_pos);
 }
-
 
 } // namespace frt

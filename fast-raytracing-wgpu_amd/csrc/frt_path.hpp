@@ -160,7 +160,8 @@ FRT_HD void path_shade(PathCtx& c, PathState& st, const HitRec& h, f3 origin, An
         st.base_color = mk3(mb.base_color[0], mb.base_color[1], mb.base_color[2]) * xyz(tex_color) * occlusion;
         if (normal_tex_id != 65535u) {   // :657-671
             f3 nm = xyz(sample_layer<false>(sc, normal_tex_id, g.uv));
-            st.ffnormal = perturb_normal(st.ffnormal, g.tangent_w, g.tangent_sign, nm);
+            f4 tg = hit_tangent(sc, g);
+            st.ffnormal = perturb_normal(st.ffnormal, xyz(tg), tg.w, nm);
         }
         if (light_index == -1 && emissive_tex_id != 65535u) {   // :675-678
             f3 emissive_col = xyz(sample_layer<true>(sc, emissive_tex_id, g.uv));

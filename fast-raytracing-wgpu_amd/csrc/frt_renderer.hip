@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <string>
 #include <vector>
+#include <cstdlib>
 
 using namespace frt;
 
@@ -23,7 +24,7 @@ static_assert(sizeof(frt_vertex_attr) == 32 && sizeof(frt_material) == 64 && siz
 static_assert(sizeof(frt_camera_uniform) == 288 && sizeof(frt_reservoir) == 32 && sizeof(frt_bvh2_node) == 32, "ABI struct sizes");
 static_assert(sizeof(CameraView) == 288 && sizeof(ReservoirView) == 32 && sizeof(InstanceView) == 64 && sizeof(InstanceDev) == 64, "view sizes");
 static_assert(sizeof(MaterialView) == 64 && sizeof(LightView) == 64 && sizeof(VertexAttrView) == 32 && sizeof(MeshInfoView) == 16, "view sizes");
-static_assert(sizeof(PairNode) == 64 && sizeof(TriSlot) == 48, "GPU layout sizes");
+static_assert(sizeof(PairNode) == 64 && sizeof(TriSlot) == 48 && sizeof(ShadeTri) == 128, "GPU layout sizes");
 
 // ------------------------------------------------------------------------------------------------ renderer object
 static const uint32_t kHaloGbuffer = 12;   // spatial reuse radius 10 (restir_spatial.wgsl:903, :921) + spatial halo 2
@@ -45,6 +46,9 @@ struct frt_renderer {
     size_t arena_bytes = 0;
     size_t off[B_COUNT] = {};
     unsigned long long* d_counters = nullptr;
+    uint32_t* d_qwords = nullptr;          // continuation queues: [stage 1|2][A|B] x kContWordsSpatial x npix words
+    uint32_t* d_qcount = nullptr;          // their 4 counters
+    uint32_t ncuts = 1, cuts[4] = {4, 0, 0, 0};   // measured best on the Cornell Box (tools/ab.py sweep: 0 / 3 / 4 / 5 / 2,4 / 4,6)
     frt_stats stats{};
     struct Timed { hipEvent_t a, b; int stage; };
     std::vector<Timed> pending;
@@ -76,6 +80,7 @@ static int upload_scene(frt_renderer* r, const SceneBuilder& b) {
     int rc;
     if ((rc = upload(r, b.pair_nodes, &sv.nodes))) return rc;
     if ((rc = upload(r, b.tri_slots, &sv.tris))) return rc;
+    if ((rc = upload(r, b.shade_tris, &sv.shade_tris))) return rc;
     if ((rc = upload(r, b.instances_dev, &sv.instances))) return rc;
     if ((rc = upload(r, b.mesh_infos, &sv.mesh_infos))) return rc;
     if ((rc = upload(r, b.attributes, &sv.attributes))) return rc;
@@ -292,6 +297,8 @@ void frt_renderer_destroy(frt_renderer* r) {
     for (void* p : r->scene_allocs) (void)hipFree(p);
     if (r->own_arena && r->arena) (void)hipFree(r->arena);
     if (r->d_counters) (void)hipFree(r->d_counters);
+    if (r->d_qwords) (void)hipFree(r->d_qwords);
+    if (r->d_qcount) (void)hipFree(r->d_qcount);
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -313,6 +320,19 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         HIP_TRY(hipMalloc((void**)&r->arena, r->arena_bytes)); r->own_arena = true;
     }
     HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
+    {   // continuation queues (worst case: every pixel parks) and the bounce depths at which paths are cut
+        size_t npix = (size_t)r->W * r->H;
+        HIP_TRY(hipMalloc((void**)&r->d_qwords, 4 * (size_t)kContWordsSpatial * npix * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&r->d_qcount, 4 * sizeof(uint32_t)));
+        if (const char* e = getenv("FRT_CUTS")) {   // experiment knob: comma-separated ascending depths, "0" = never cut
+            r->ncuts = 0;
+            for (const char* p = e; *p && r->ncuts < 4;) {
+                uint32_t v = (uint32_t)strtoul(p, (char**)&p, 10);
+                if (v >= 1) r->cuts[r->ncuts++] = v;
+                if (*p == ',') ++p;
+            }
+        }
+    }
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));   // wgpu zero-initialises textures and buffers
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, 8 * sizeof(unsigned long long), r->stream));
     int rc = upload_scene(r, s->b);
@@ -345,6 +365,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
     fill_frame_view(r, cam, fv);
     uint32_t rows[8];
     phase_rows(r, rows);
+    if (phases & (FRT_PHASE_TEMPORAL | FRT_PHASE_SPATIAL)) HIP_TRY(hipMemsetAsync(r->d_qcount, 0, 4 * sizeof(uint32_t), r->stream));
     for (int stage = 0; stage < 4; ++stage) {
         if (!(phases & (1 << stage))) continue;
         fv.y0 = rows[2 * stage]; fv.y1 = rows[2 * stage + 1];
@@ -355,7 +376,19 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
             HIP_TRY(hipEventCreate(&t.a)); HIP_TRY(hipEventCreate(&t.b)); t.stage = stage;
             HIP_TRY(hipEventRecord(t.a, r->stream));
         }
-        HIP_TRY(launch_stage(stage, r->sv, fv, r->stream, (r->flags & FRT_FLAG_COMPACTION) != 0));
+        StageLaunch L{};
+        L.compaction = (r->flags & FRT_FLAG_COMPACTION) != 0;
+        L.ncuts = r->ncuts;
+        for (int k = 0; k < 4; ++k) L.cuts[k] = r->cuts[k];
+        if (stage == 1 || stage == 2) {
+            size_t npix = (size_t)r->W * r->H, qsz = (size_t)kContWordsSpatial * npix;
+            for (int k = 0; k < 2; ++k) {
+                L.queues[k].words = r->d_qwords + (size_t)(2 * (stage - 1) + k) * qsz;
+                L.queues[k].count = r->d_qcount + 2 * (stage - 1) + k;
+                L.queues[k].capacity = (uint32_t)npix;
+            }
+        }
+        HIP_TRY(launch_stage(stage, r->sv, fv, r->stream, L));
         if (timed) { HIP_TRY(hipEventRecord(t.b, r->stream)); r->pending.push_back(t); }
         r->stats.launches[stage] += 1;
     }

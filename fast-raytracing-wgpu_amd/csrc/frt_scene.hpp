@@ -65,6 +65,8 @@ struct TriRec { float v0[3], e1[3], e2[3]; };
 struct PairNode { float q[16]; };
 // Triangle slot, 48 B, in leaf order: (v0.xyz, flattened id bits) (e1.xyz, instance index bits) (e2.xyz, 0)
 struct TriSlot { float q[12]; };
+// Shading record, 128 B per flattened triangle (frt_shade.hpp: fetch_hit_geometry)
+struct ShadeTri { float q[32]; };
 struct InstanceDev { uint32_t mesh_id, mat_id, first_tri, flip; float w2o[9]; float pad[3]; };   // 64 B
 
 static const uint32_t kLeafFlag = 0x80000000u;
@@ -105,6 +107,7 @@ public:
     uint32_t bvh_depth = 0, bvh_leaves = 0, bvh_max_leaf = 0;
     std::vector<PairNode> pair_nodes;
     std::vector<TriSlot> tri_slots;
+    std::vector<ShadeTri> shade_tris;
     std::vector<InstanceDev> instances_dev;
     float srgb_lut[256];
     std::string error;

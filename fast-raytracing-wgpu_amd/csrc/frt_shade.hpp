@@ -32,6 +32,7 @@ struct FrameView {
 };
 
 static constexpr float kPI = 3.14159265359f;   // restir.wgsl:4
+static constexpr float kInvPI = 1.0f / kPI;    // x / PI is evaluated as x * (1 / PI) (contract)
 
 struct PathCtx {
     const SceneView& sc;
@@ -100,12 +101,12 @@ FRT_HD void make_orthonormal_basis(f3 n, f3& tangent, f3& bitangent) {   // rest
     bitangent = mk3(b, sign + n.y * n.y * a, -n.y);
 }
 FRT_HD f3 fresnel_schlick(f3 f0, float v_dot_h) {   // :170
-    return f0 + (1.0f - f0) * powf_(clampf(1.0f - v_dot_h, 0.0f, 1.0f), 5.0f);
+    return f0 + (1.0f - f0) * pow5_(clampf(1.0f - v_dot_h, 0.0f, 1.0f));
 }
 FRT_HD float reflectance(float cosine, float ref_idx) {   // :175
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
     r0 = r0 * r0;
-    return r0 + (1.0f - r0) * powf_(1.0f - cosine, 5.0f);
+    return r0 + (1.0f - r0) * pow5_(1.0f - cosine);
 }
 FRT_HD float ndf_ggx(float n_dot_h, float roughness) {   // :182
     float a = roughness * roughness;
@@ -186,7 +187,7 @@ FRT_HD float eval_pdf(f3 normal, f3 wi, f3 wo, const MatParams& m, f3 base_color
     float d = ndf_ggx(n_dot_h, m.roughness);
     float g1 = geometry_schlick_ggx(n_dot_v, m.roughness);
     float pdf_spec = (d * g1) / (4.0f * n_dot_v);
-    float pdf_diff = fmaxn(n_dot_l, 0.0f) / kPI;
+    float pdf_diff = fmaxn(n_dot_l, 0.0f) * kInvPI;
     return prob_spec * pdf_spec + (1.0f - prob_spec) * pdf_diff;
 }
 FRT_HD f3 eval_bsdf(f3 normal, f3 wi, f3 wo, const MatParams& m, f3 base_color) {   // :278-305
@@ -256,34 +257,42 @@ FRT_HD BsdfSmp sample_bsdf(PathCtx& c, f3 wo, f3 ffnormal, bool front_face, cons
 }
 
 // Attribute fetch + interpolation for a committed hit: gbuffer.wgsl:124-174 and restir.wgsl:383-441
-struct HitGeom { f3 normal_w, tangent_w; f2 uv; float tangent_sign; uint32_t mat_id; };
+// Attribute fetch + interpolation for a committed hit: gbuffer.wgsl:124-174 and restir.wgsl:383-441.
+// The reference walks instance -> mesh_infos -> indices -> attributes (four dependent loads) and decodes three octahedral normals
+// per hit. Here the host flattens that chain once per triangle into a 128-byte shading record indexed by the flattened triangle id
+// (decoded vertex normals, tangents, uvs, tangent sign, material id): one level of 16-byte loads, issued together with the
+// instance's world_to_object. The decoded normals are produced by the very function below compiled for the host, so the
+// values are bit-identical to decoding on the fly.
+//   q0 (n0.xyz, uv0.x) q1 (n1.xyz, uv0.y) q2 (n2.xyz, uv1.x) q3 (t0.xyz, uv1.y) q4 (t1.xyz, uv2.x) q5 (t2.xyz, uv2.y) q6 (tangent_sign, mat_id, -, -)
+struct HitGeom { f3 normal_w; f2 uv; uint32_t mat_id; float u, v; uint32_t tri, inst; };
 FRT_HD HitGeom fetch_hit_geometry(const SceneView& sc, const HitRec& h) {
+    const float4* rec = sc.shade_tris + (size_t)h.tri * 8u;
+    float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q6 = rec[6];
     const InstanceView& in = sc.instances[h.inst];
-    uint32_t prim = h.tri - in.first_tri;
-    MeshInfoView mi = sc.mesh_infos[in.mesh_id];
-    uint32_t io = mi.index_offset + prim * 3u;
-    uint32_t i0 = sc.indices[io + 0u] + mi.vertex_offset;
-    uint32_t i1 = sc.indices[io + 1u] + mi.vertex_offset;
-    uint32_t i2 = sc.indices[io + 2u] + mi.vertex_offset;
-    const VertexAttrView &a0 = sc.attributes[i0], &a1 = sc.attributes[i1], &a2 = sc.attributes[i2];
-    f3 n0 = decode_octahedral_normal(a0.normal[0], a0.normal[1]);
-    f3 n1 = decode_octahedral_normal(a1.normal[0], a1.normal[1]);
-    f3 n2 = decode_octahedral_normal(a2.normal[0], a2.normal[1]);
-    f3 t0 = mk3(a0.tangent[0], a0.tangent[1], a0.tangent[2]);
-    f3 t1 = mk3(a1.tangent[0], a1.tangent[1], a1.tangent[2]);
-    f3 t2 = mk3(a2.tangent[0], a2.tangent[1], a2.tangent[2]);
+    f3 n0 = mk3(q0.x, q0.y, q0.z), n1 = mk3(q1.x, q1.y, q1.z), n2 = mk3(q2.x, q2.y, q2.z);
+    float4 q3 = rec[3], q4 = rec[4], q5 = rec[5];
     float u = h.u, v = h.v, w = 1.0f - u - v;
     f3 local_normal = normalize(n0 * w + n1 * u + n2 * v);
-    f3 local_tangent = normalize(t0 * w + t1 * u + t2 * v);
     HitGeom g;
-    g.uv = mk2(a0.uv[0], a0.uv[1]) * w + mk2(a1.uv[0], a1.uv[1]) * u + mk2(a2.uv[0], a2.uv[1]) * v;
+    g.uv = mk2(q0.w, q1.w) * w + mk2(q2.w, q3.w) * u + mk2(q4.w, q5.w) * v;
     // v * mat3x3(w2o[0], w2o[1], w2o[2]) = (dot(v, col0), dot(v, col1), dot(v, col2))
     f3 c0 = mk3(in.w2o[0], in.w2o[1], in.w2o[2]), c1 = mk3(in.w2o[3], in.w2o[4], in.w2o[5]), c2 = mk3(in.w2o[6], in.w2o[7], in.w2o[8]);
     g.normal_w = normalize(mk3(dot(local_normal, c0), dot(local_normal, c1), dot(local_normal, c2)));
-    g.tangent_w = normalize(mk3(dot(local_tangent, c0), dot(local_tangent, c1), dot(local_tangent, c2)));
-    g.tangent_sign = a0.tangent[3];
-    g.mat_id = in.mat_id;
+    g.mat_id = f2u(q6.y);
+    g.u = u; g.v = v; g.tri = h.tri; g.inst = h.inst;
     return g;
+}
+// World-space tangent + sign of the hit: only needed under a normal map (gbuffer.wgsl:152-160, restir.wgsl:423-432), so it is
+// evaluated lazily; the value is the one the reference computes unconditionally.
+FRT_HD f4 hit_tangent(const SceneView& sc, const HitGeom& g) {
+    const float4* rec = sc.shade_tris + (size_t)g.tri * 8u;
+    float4 q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+    const InstanceView& in = sc.instances[g.inst];
+    float w = 1.0f - g.u - g.v;
+    f3 local_tangent = normalize(mk3(q3.x, q3.y, q3.z) * w + mk3(q4.x, q4.y, q4.z) * g.u + mk3(q5.x, q5.y, q5.z) * g.v);
+    f3 c0 = mk3(in.w2o[0], in.w2o[1], in.w2o[2]), c1 = mk3(in.w2o[3], in.w2o[4], in.w2o[5]), c2 = mk3(in.w2o[6], in.w2o[7], in.w2o[8]);
+    f3 tw = normalize(mk3(dot(local_tangent, c0), dot(local_tangent, c1), dot(local_tangent, c2)));
+    return mk4(tw, q6.x);
 }
 FRT_HD f3 perturb_normal(f3 N_ff, f3 tangent_w, float tangent_sign, f3 nm) {   // gbuffer.wgsl:206-219, restir.wgsl:657-671
     f3 normal_local = normalize(nm * 2.0f - splat3(1.0f));
@@ -329,7 +338,8 @@ FRT_HD void gbuffer_pixel(PathCtx& c, uint32_t px, uint32_t py) {
     f3 final_normal = ffnormal;
     if (normal_tex_id != 65535u) {
         f3 nm = xyz(sample_layer<false>(sc, normal_tex_id, g.uv));
-        final_normal = perturb_normal(ffnormal, g.tangent_w, g.tangent_sign, nm);
+        f4 tg = hit_tangent(sc, g);
+        final_normal = perturb_normal(ffnormal, xyz(tg), tg.w, nm);
     }
     f3 base_color = mk3(mat.base_color[0], mat.base_color[1], mat.base_color[2]) * xyz(tex_color) * occlusion;
     m4 view_proj = load_m4(fv.cam.view_proj), prev_view_proj = load_m4(fv.cam.prev_view_proj);
@@ -384,7 +394,7 @@ FRT_HD void post_pixel(const FrameView& fv, uint32_t px, uint32_t py) {
             float w_spatial = gauss(length2(mk2((float)dx, (float)dy)), 1.5f);
             float w_color = gauss(length(sample_albedo - center_albedo), 0.2f);
             float dot_normal = clampf(dot(center_normal, sample_normal), 0.0f, 1.0f);
-            float w_normal = powf_(dot_normal, 20.0f);
+            float w_normal = pow20_(dot_normal);
             float w_pos = gauss(length(sample_pos - center_pos), 0.1f);
             float weight = w_spatial * w_color * w_normal * w_pos;
             sum_color = sum_color + sample_color * weight;

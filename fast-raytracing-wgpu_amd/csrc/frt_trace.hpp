@@ -28,6 +28,7 @@ struct LightView { float position[3]; uint32_t type_; float u[3]; float area; fl
 struct SceneView {
     const float4* nodes;        // pair nodes, 4 x float4 each
     const float4* tris;         // triangle slots, 3 x float4 each
+    const float4* shade_tris;   // shading records, 8 x float4 per flattened triangle id (frt_shade.hpp: fetch_hit_geometry)
     const InstanceView* instances;
     const MeshInfoView* mesh_infos;
     const VertexAttrView* attributes;

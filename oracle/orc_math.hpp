@@ -40,7 +40,8 @@ inline vec3 operator-(vec3 a) { return {-a.x, -a.y, -a.z}; }
 inline vec3 operator*(vec3 a, vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 inline vec3 operator*(vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 inline vec3 operator*(float s, vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
-inline vec3 operator/(vec3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+// vector / scalar: one IEEE reciprocal, then three multiplies (contract; WGSL allows 2.5 ulp for division)
+inline vec3 operator/(vec3 a, float s) { float r = 1.0f / s; return {a.x * r, a.y * r, a.z * r}; }
 inline vec3 operator/(vec3 a, vec3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
 inline vec3 operator+(vec3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
 inline vec3 operator-(float s, vec3 a) { return {s - a.x, s - a.y, s - a.z}; }
@@ -175,6 +176,9 @@ inline float log2_(float x) {
     return r + (float)e;
 }
 
+// pow(x, 5) / pow(x, 20) of the shaders by repeated multiplication (contract), x >= 0 at every call site
+inline float pow5_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x; }
+inline float pow20_(float x) { float x2 = x * x; float x4 = x2 * x2; float x8 = x4 * x4; float x16 = x8 * x8; return x16 * x4; }
 // pow(x, y) for the shader uses (y > 0): x <= 0 (or NaN) -> 0.
 inline float pow_(float x, float y) {
     if (!(x > 0.0f)) return 0.0f;

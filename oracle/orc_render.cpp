@@ -125,12 +125,12 @@ static void make_orthonormal_basis(vec3 n, vec3& tangent, vec3& bitangent) {
     bitangent = V3(b, sign + n.y * n.y * a, -n.y);
 }
 static vec3 fresnel_schlick(vec3 f0, float v_dot_h) {   // :170-172
-    return f0 + (1.0f - f0) * pow_(clamp_(1.0f - v_dot_h, 0.0f, 1.0f), 5.0f);
+    return f0 + (1.0f - f0) * pow5_(clamp_(1.0f - v_dot_h, 0.0f, 1.0f));
 }
 static float reflectance(float cosine, float ref_idx) {   // :175-180
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
     r0 = r0 * r0;
-    return r0 + (1.0f - r0) * pow_(1.0f - cosine, 5.0f);
+    return r0 + (1.0f - r0) * pow5_(1.0f - cosine);
 }
 static float ndf_ggx(float n_dot_h, float roughness) {   // :182-187
     float a = roughness * roughness;
@@ -202,7 +202,7 @@ static float eval_pdf(vec3 normal, vec3 wi, vec3 wo, const Material& mat, vec3 b
     float d = ndf_ggx(n_dot_h, mat.roughness);
     float g1 = geometry_schlick_ggx(n_dot_v, mat.roughness);
     float pdf_spec = (d * g1) / (4.0f * n_dot_v);
-    float pdf_diff = fmax_(n_dot_l, 0.0f) / PI;
+    float pdf_diff = fmax_(n_dot_l, 0.0f) * (1.0f / PI);   // x / PI evaluated as x * (1 / PI) (contract)
     return prob_spec * pdf_spec + (1.0f - prob_spec) * pdf_diff;
 }
 static vec3 eval_bsdf(vec3 normal, vec3 wi, vec3 wo, const Material& mat, vec3 base_color) {   // :278-305
@@ -817,7 +817,7 @@ static void post_pixel(Ctx& c, Renderer& R, uint32_t px, uint32_t py) {
             float dist_color = length(sample_albedo - center_albedo);
             float w_color = gauss(dist_color, sigma_color);
             float dot_normal = clamp_(dot(center_normal, sample_normal), 0.0f, 1.0f);
-            float w_normal = pow_(dot_normal, 20.0f);
+            float w_normal = pow20_(dot_normal);
             float dist_pos = length(sample_pos - center_pos);
             float w_pos = gauss(dist_pos, sigma_pos);
             float weight = w_spatial * w_color * w_normal * w_pos;

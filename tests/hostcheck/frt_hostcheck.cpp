@@ -26,6 +26,55 @@ struct HostCheck {
 };
 }
 
+// One stage through the cut / park / resume protocol of the continuation kernels, sequentially: every pixel runs head + bounces
+// [1, cut), survivors are parked in a host-side ContQueue, then each parked path is resumed for [cut, cut2) and [cut2, max).
+template <int STAGE>
+static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned long long rc[2]) {
+    const uint32_t npix = h->W * h->H;
+    std::vector<uint32_t> wa((size_t)kContWordsSpatial * npix), wb((size_t)kContWordsSpatial * npix);
+    uint32_t ca = 0, cb = 0;
+    ContQueue qa{wa.data(), &ca, npix}, qb{wb.data(), &cb, npix};
+    uint32_t stack[kStackDepth];
+    constexpr int V = STAGE == 1 ? 0 : 1;
+    for (uint32_t pix = 0; pix < npix; ++pix) {
+        PathCtx c(h->sv, fv, stack, 1u);
+        ReservoirView r = zero_reservoir();
+        uint32_t seed;
+        if (STAGE == 1) {
+            if (fv.gpos[pix].w < 0.0f) { fv.res_temporal[pix] = zero_reservoir(); continue; }
+            seed = temporal_seed(fv, pix);
+        } else {
+            if (!spatial_neighbors(c, pix, r)) { rc[1] += c.n_any; continue; }
+            seed = r.y;
+        }
+        LoopState s;
+        path_head<V>(c, pix, seed, s);
+        if (s.alive) path_loop<V>(c, s, 1u, cut < fv.max_depth ? cut : fv.max_depth);
+        rc[0] += c.n_closest; rc[1] += c.n_any;
+        if (s.alive) cont_store(qa, ca++, pix, c.rng, true, s, STAGE == 2 ? &r : nullptr);
+        else if (STAGE == 1) { PathState st; make_path_state(st, pix, s.accumulated, s.v1_pos); temporal_finalize(c, st); }
+        else spatial_tail(c, pix, r, s.accumulated, s.v1_pos);
+    }
+    uint32_t d0 = cut;
+    ContQueue* qin = &qa; ContQueue* qout = &qb;
+    while (*qin->count > 0) {
+        uint32_t d1 = d0 + 2u < fv.max_depth ? d0 + 2u : fv.max_depth;
+        *qout->count = 0;
+        for (uint32_t slot = 0; slot < *qin->count; ++slot) {
+            PathCtx c(h->sv, fv, stack, 1u);
+            LoopState s; ReservoirView r = zero_reservoir(); uint32_t pix; bool owned;
+            cont_load(*qin, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+            path_loop<V>(c, s, d0, d1);
+            rc[0] += c.n_closest; rc[1] += c.n_any;
+            if (s.alive) { cont_store(*qout, (*qout->count)++, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr); }
+            else if (STAGE == 1) { PathState st; make_path_state(st, pix, s.accumulated, s.v1_pos); temporal_finalize(c, st); }
+            else spatial_tail(c, pix, r, s.accumulated, s.v1_pos);
+        }
+        std::swap(qin, qout);
+        d0 = d1;
+    }
+}
+
 extern "C" {
 
 void* hc_create(const frt_scene* s, uint32_t W, uint32_t H, uint32_t max_depth, int nthreads) {
@@ -37,6 +86,7 @@ void* hc_create(const frt_scene* s, uint32_t W, uint32_t H, uint32_t max_depth, 
     SceneView& sv = h->sv;
     sv.nodes = reinterpret_cast<const float4*>(b.pair_nodes.data());
     sv.tris = reinterpret_cast<const float4*>(b.tri_slots.data());
+    sv.shade_tris = reinterpret_cast<const float4*>(b.shade_tris.data());
     sv.instances = reinterpret_cast<const InstanceView*>(b.instances_dev.data());
     sv.mesh_infos = reinterpret_cast<const MeshInfoView*>(b.mesh_infos.data());
     sv.attributes = reinterpret_cast<const VertexAttrView*>(b.attributes.data());
@@ -56,7 +106,8 @@ void* hc_create(const frt_scene* s, uint32_t W, uint32_t H, uint32_t max_depth, 
 }
 void hc_destroy(void* p) { delete (HostCheck*)p; }
 
-// sm != 0: drive the resumable state machine (frt_path.hpp) instead of the straight-line functions (frt_mono.hpp)
+// sm == 1: drive the resumable state machine (frt_path.hpp) instead of the straight-line functions (frt_mono.hpp);
+// sm >= 2: straight-line functions cut at bounce depth `sm` with the continuation-queue protocol (run_stage_cut)
 void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     HostCheck* h = (HostCheck*)p;
     uint32_t cur = h->frame_count & 1u, prv = cur ^ 1u;
@@ -71,14 +122,20 @@ void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     int nt = h->nthreads;
     std::vector<unsigned long long> rc((size_t)nt * 2, 0ull);
     for (int stage = 0; stage < 4; ++stage) {
+        if (sm >= 2 && (stage == 1 || stage == 2)) {
+            unsigned long long r2[2] = {0, 0};
+            if (stage == 1) run_stage_cut<1>(h, fv, (uint32_t)sm, r2); else run_stage_cut<2>(h, fv, (uint32_t)sm, r2);
+            h->rays[0] += r2[0]; h->rays[1] += r2[1];
+            continue;
+        }
         auto work = [&](int tid) {
             uint32_t stack[kStackDepth];
             for (uint32_t y = (uint32_t)tid; y < h->H; y += (uint32_t)nt)
                 for (uint32_t x = 0; x < h->W; ++x) {
                     PathCtx c(h->sv, fv, stack, 1u);
                     if (stage == 0) gbuffer_pixel(c, x, y);
-                    else if (stage == 1) { if (sm) temporal_pixel_sm(c, x, y); else temporal_pixel(c, x, y); }
-                    else if (stage == 2) { if (sm) spatial_pixel_sm(c, x, y); else spatial_pixel(c, x, y); }
+                    else if (stage == 1) { if (sm == 1) temporal_pixel_sm(c, x, y); else temporal_pixel(c, x, y); }
+                    else if (stage == 2) { if (sm == 1) spatial_pixel_sm(c, x, y); else spatial_pixel(c, x, y); }
                     else post_pixel(fv, x, y);
                     rc[2 * tid] += c.n_closest; rc[2 * tid + 1] += c.n_any;
                 }
