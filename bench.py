@@ -103,14 +103,16 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from frt.dist import StripPlan, ArenaRows, exchange_halos
+    from frt.dist import StripPlan, ArenaRows, exchange_halos, balanced_boundaries
     scene = frt.scenes.create_cornell_box()
     nl = scene.num_lights
     total = a.warmup + a.steps
     cam_ctl = frt.CameraController()
     cams = [cam_ctl.build_uniform(W / H, f, nl) for f in range(max(total, a.cpu_frames + 1))]
 
-    plan = StripPlan(H, world, rank)
+    # strips of equal WORK (probe render, identical on every rank), not equal height
+    bounds = balanced_boundaries(frt, scene, W, H, world, max_depth=MAX_DEPTH, device=local_rank) if world > 1 else None
+    plan = StripPlan(H, world, rank, bounds)
     nbytes = frt.Renderer.arena_bytes(W, H)
     arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device=f"cuda:{local_rank}")
     off = (-arena.data_ptr()) % 256
@@ -179,7 +181,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell Box 1920x1080, MAX_DEPTH 8, 1 candidate path/pixel/frame, 4-stage ReSTIR-PT frame (BASELINE.json configs[1])",
-                       "rays_per_frame": rays / a.steps, "parallelism": "1 GPU" if world == 1 else f"{world} image strips, 1 halo exchange/frame (RCCL)"},
+                       "rays_per_frame": rays / a.steps, "parallelism": "1 GPU" if world == 1 else f"{world} work-balanced image strips {bounds}, 1 halo exchange/frame (RCCL)"},
             "roofline": {"bound": "hbm", "kernel": {0: "gbuffer_kernel", 1: "pixel_kernel<1> (temporal)", 2: "pixel_kernel<2> (spatial + shade)", 3: "post_kernel"}[dom], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(name) if world == 1 else None,
                          "avg_launch_ms": ms[dom], "algorithmic_bytes_per_launch": algo_bytes,

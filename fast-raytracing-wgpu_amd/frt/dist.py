@@ -21,15 +21,20 @@ BUF_RESERVOIR, BUF_ACCUM = 4, 7
 
 
 class StripPlan:
-    """Rows [row_begin, row_end) of an image of height H owned by `rank` of `world`."""
+    """Rows [row_begin, row_end) of an image of height H owned by `rank` of `world`.
 
-    def __init__(self, height, world, rank):
+    boundaries: optional list of world + 1 ascending row indices (0 ... H), e.g. from balanced_boundaries(); default = equal strips."""
+
+    def __init__(self, height, world, rank, boundaries=None):
         assert 0 <= rank < world
         self.H, self.world, self.rank = height, world, rank
-        self.row_begin = height * rank // world
-        self.row_end = height * (rank + 1) // world
-        if world > 1 and self.row_end - self.row_begin < HALO_RESERVOIR:
-            raise ValueError(f"strip of {self.row_end - self.row_begin} rows is thinner than the {HALO_RESERVOIR}-row halo")
+        if boundaries is None:
+            boundaries = [height * k // world for k in range(world + 1)]
+        assert len(boundaries) == world + 1 and boundaries[0] == 0 and boundaries[-1] == height
+        self.boundaries = list(boundaries)
+        self.row_begin, self.row_end = boundaries[rank], boundaries[rank + 1]
+        if world > 1 and min(b - a for a, b in zip(boundaries, boundaries[1:])) < HALO_RESERVOIR:
+            raise ValueError(f"a strip is thinner than the {HALO_RESERVOIR}-row halo: {boundaries}")
 
     def transfers(self, frame):
         """[(peer, buf, index, send_rows, recv_rows)] for the exchange of frame `frame` (before its spatial stage)."""
@@ -104,9 +109,48 @@ def exchange_halos_host(renderers, plans, frame):
 
 
 def gather_strips(local_rows_tensor, plan, group=None):
-    """All-gather of equally sized strip tensors into the full frame (in-place layout: strip k at rows [k*h, (k+1)*h))."""
+    """All-gather of the strips ([rows, ...] tensors, possibly of different heights) into the full frame."""
     import torch
     import torch.distributed as dist
-    parts = [torch.empty_like(local_rows_tensor) for _ in range(plan.world)]
-    dist.all_gather(parts, local_rows_tensor, group=group)
-    return torch.cat(parts, dim=0)
+    heights = [b - a for a, b in zip(plan.boundaries, plan.boundaries[1:])]
+    hmax = max(heights)
+    pad = torch.zeros((hmax,) + tuple(local_rows_tensor.shape[1:]), dtype=local_rows_tensor.dtype, device=local_rows_tensor.device)
+    pad[:local_rows_tensor.shape[0]] = local_rows_tensor
+    parts = [torch.empty_like(pad) for _ in range(plan.world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:h] for p, h in zip(parts, heights)], dim=0)
+
+
+def balanced_boundaries(frt, scene, width, height, world, max_depth=8, bands=36, probe_frames=2, device=0):
+    """Strip boundaries that equalise work instead of rows (the ceiling strip of a Cornell Box is far cheaper than the floor strip).
+
+    Every rank runs the same probe: a quarter-resolution render, band by band, reading the exact device ray counters of each band
+    (integers, so all ranks compute identical boundaries without talking to each other). Cost model: rays + 4 per pixel.
+    The image does not depend on the partition (tests: strips == whole image, bit for bit), only the time does."""
+    if world == 1:
+        return [0, height]
+    pw, ph = max(width // 4, 16), max(height // 4, bands)
+    cost = []
+    for b in range(bands):
+        y0, y1 = ph * b // bands, ph * (b + 1) // bands
+        r = frt.Renderer(scene, pw, ph, max_depth=max_depth, device=device, rows=(y0, y1))
+        cam = frt.CameraController()
+        for _ in range(probe_frames):
+            r.render(cam.build_uniform(width / height, r.frame_count, scene.num_lights))
+        st = r.stats()
+        cost.append(st["rays_closest"] + st["rays_any"] + 4 * pw * (y1 - y0) * probe_frames)
+        del r
+    # cumulative cost over full-resolution rows (piecewise linear inside a band)
+    row_cost = np.zeros(height)
+    for b in range(bands):
+        y0, y1 = height * b // bands, height * (b + 1) // bands
+        row_cost[y0:y1] = cost[b] / max(y1 - y0, 1)
+    cum = np.concatenate([[0.0], np.cumsum(row_cost)])
+    bounds = [0]
+    for k in range(1, world):
+        y = int(np.searchsorted(cum, cum[-1] * k / world))
+        y = max(y, bounds[-1] + HALO_RESERVOIR)                       # every strip at least as tall as the halo
+        y = min(y, height - HALO_RESERVOIR * (world - k))
+        bounds.append(y)
+    bounds.append(height)
+    return bounds

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--mode", default="oracle"); ap.add_argument("--rank", type=int); ap.add_argument("--world", type=int)
     ap.add_argument("--port", type=int); ap.add_argument("--out"); ap.add_argument("--W", type=int, default=96)
     ap.add_argument("--H", type=int, default=64); ap.add_argument("--frames", type=int, default=4)
+    ap.add_argument("--balanced", type=int, default=0)
     a = ap.parse_args()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world))
     import torch
@@ -40,8 +41,12 @@ def main():
     from _oracle import Oracle
     dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
     W, H, N = a.W, a.H, a.frames
-    plan = StripPlan(H, a.world, a.rank)
     fs = frt.scenes.create_cornell_box()
+    bounds = None
+    if a.balanced:
+        from frt.dist import balanced_boundaries
+        bounds = balanced_boundaries(frt, fs, W, H, a.world, bands=8)
+    plan = StripPlan(H, a.world, a.rank, bounds)
     cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(N)]
     orc = Oracle(os.path.join(ROOT, "oracle", "_build", "liborc.so"))
     osc = orc.cornell(); osc.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
@@ -82,7 +87,7 @@ def main():
         for f in range(N):
             ref.render(cams[f])
         want = ref.read(7, (N - 1) % 2)
-        res = {"ok": bool(full.tobytes() == want.tobytes()), "mismatch_pixels": int((full.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())}
+        res = {"bounds": plan.boundaries, "ok": bool(full.tobytes() == want.tobytes()), "mismatch_pixels": int((full.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())}
         if rays is not None:
             so = ref.stats()["total"]; res["oracle_rays"] = so["closest"] + so["any"]
     if rays is not None:

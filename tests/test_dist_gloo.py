@@ -52,3 +52,11 @@ def test_strip_plan_geometry(frt):
     assert len(plans[0].transfers(0)) == 1 and len(plans[3].transfers(2)) == 4
     with pytest.raises(ValueError):
         StripPlan(64, 8, 0)
+    # unequal (work-balanced) strips
+    p = [StripPlan(100, 3, k, [0, 50, 70, 100]) for k in range(3)]
+    assert (p[1].row_begin, p[1].row_end) == (50, 70)
+    sends = {(q.rank, peer, buf, idx, s) for q in p for peer, buf, idx, s, r in q.transfers(1)}
+    recvs = {(peer, q.rank, buf, idx, r) for q in p for peer, buf, idx, s, r in q.transfers(1)}
+    assert sends == recvs
+    with pytest.raises(ValueError):
+        StripPlan(100, 3, 0, [0, 50, 55, 100])

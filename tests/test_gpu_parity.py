@@ -171,3 +171,7 @@ def test_two_rank_strips_through_torch_distributed(gpu, tmp_path):
     res = run_ranks("gpu", 2, tmp_path, ("--H", "96", "--W", "160", "--frames", "5"))
     assert res["ok"], res
     assert res["rays_all_ranks"] == res["oracle_rays"]
+    # work-balanced (unequal) strips from the probe render give the same image
+    res = run_ranks("gpu", 2, tmp_path, ("--H", "128", "--W", "160", "--frames", "4", "--balanced", "1"))
+    assert res["ok"] and res["rays_all_ranks"] == res["oracle_rays"], res
+    assert res["bounds"][1] != 64, res
