@@ -30,10 +30,10 @@ STAGES = ("gbuffer", "temporal", "spatial", "post")
 # Compulsory per-pixel stream bytes of each kernel in this design: G-buffer write 44; temporal read 44+36+32,
 # write 32; spatial read 36+32, write 32+8; post read 68, write 20.
 B_PX = {"gbuffer": 44, "temporal": 144, "spatial": 108, "post": 88}
-# HBM bytes per launch at 1920x1080 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r1_v4_pmc.txt),
+# HBM bytes per launch at 1920x1080 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r1_v5_pmc.txt),
 # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM. Measured offline, not in this run.
-PMC_TRAFFIC_BYTES = {"gbuffer": (2 * 2255 + 89360) * 1024, "temporal": (2 * 128900 + 86890) * 1024,
-                     "spatial": (2 * 159700 + 82890) * 1024, "post": (2 * 226100 + 40630) * 1024}
+PMC_TRAFFIC_BYTES = {"gbuffer": (2 * 2250 + 89360) * 1024, "temporal": (2 * (138000 + 58900) + 108000 + 8688) * 1024,
+                     "spatial": (2 * (166300 + 22260) + 122300 + 15210) * 1024, "post": (2 * 239600 + 40830) * 1024}
 
 
 def cpu_share():
@@ -182,9 +182,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell Box 1920x1080, MAX_DEPTH 8, 1 candidate path/pixel/frame, 4-stage ReSTIR-PT frame (BASELINE.json configs[1])",
                        "rays_per_frame": rays / a.steps, "parallelism": "1 GPU" if world == 1 else f"{world} work-balanced image strips {bounds}, 1 halo exchange/frame (RCCL)"},
-            "roofline": {"bound": "hbm", "kernel": {0: "gbuffer_kernel", 1: "pixel_kernel<1> (temporal)", 2: "pixel_kernel<2> (spatial + shade)", 3: "post_kernel"}[dom], "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": {0: "gbuffer_kernel", 1: "temporal stage = pixel_kernel<1> + continue_kernel<1>", 2: "spatial + shade stage = pixel_kernel<2> + continue_kernel<2>", 3: "post_kernel"}[dom], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(name) if world == 1 else None,
-                         "avg_launch_ms": ms[dom], "algorithmic_bytes_per_launch": algo_bytes,
+                         "avg_launch_ms": ms[dom], "launches_per_step": 2 if dom in (1, 2) else 1, "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_ray": 32.0 * npr + 48.0 * tpr, "rays_per_launch": stage_rays[dom],
                          "note": "scene (91 KB) is L2-resident; HBM sees only the per-pixel streams, so the HBM fraction is small by construction (SURVEY F9)"},
             "stage_ms": dict(zip(STAGES, ms)),
