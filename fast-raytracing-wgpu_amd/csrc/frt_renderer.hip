@@ -324,6 +324,10 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         size_t npix = (size_t)r->W * r->H;
         HIP_TRY(hipMalloc((void**)&r->d_qwords, 4 * (size_t)kContWordsSpatial * npix * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&r->d_qcount, 4 * sizeof(uint32_t)));
+        // Parking pays when the launch saturates the chip (>= ~0.6 M pixels: +6 % at 1080p, +5 % at half a frame); a thin strip
+        // is bound by the latency of its longest path and the extra launch only adds to it (tools/strip_time.py: 0.79 vs 0.70 ms
+        // for 1/8 of a 1080p frame), so thin strips run uncut.
+        if ((size_t)r->W * (r->re - r->rb) < 600000u) r->ncuts = 0;
         if (const char* e = getenv("FRT_CUTS")) {   // experiment knob: comma-separated ascending depths, "0" = never cut
             r->ncuts = 0;
             for (const char* p = e; *p && r->ncuts < 4;) {

@@ -123,3 +123,32 @@ def colonnade(frt, orc, nx=12, nz=4, subdiv=4):
             b.add_instance(cube, stone, _mat(x, -0.35, z, 0.18, 1.3, 0.18))
             b.add_instance(sph, stone, _mat(x, 0.42, z, 0.45, 0.3, 0.45))
     return b.build()
+
+
+def moving_camera_uniforms(frt, aspect, num_lights, frames, step=(0.02, 0.01, -0.03), yaw_step=0.01):
+    """CameraUniform sequence for a camera that moves and turns every frame (the half of temporal / post logic the static
+    benchmark never reaches: non-zero motion vectors, reprojection to other pixels, the TAA clamp branch).
+    Built in numpy following camera.rs:207-256: view_proj, inverses, and prev_view_proj = the previous frame's view_proj."""
+    out = []
+    prev_vp = None
+    for f in range(frames):
+        eye = np.array([0.0 + step[0] * f, 0.0 + step[1] * f, 3.0 + step[2] * f])
+        yaw = -np.pi / 2 + yaw_step * f
+        fwd = np.array([np.cos(yaw), 0.0, np.sin(yaw)])
+        s = np.cross(fwd, [0, 1, 0]); s /= np.linalg.norm(s)
+        u = np.cross(s, fwd)
+        view = np.eye(4)
+        view[0, :3], view[1, :3], view[2, :3] = s, u, -fwd
+        view[0, 3], view[1, 3], view[2, 3] = -eye @ s, -eye @ u, eye @ fwd
+        h = 1.0 / np.tan(np.radians(45.0) / 2); r = 100.0 / (0.1 - 100.0)
+        proj = np.zeros((4, 4)); proj[0, 0] = h / aspect; proj[1, 1] = h; proj[2, 2] = r; proj[2, 3] = r * 0.1; proj[3, 2] = -1.0
+        vp = proj @ view
+        cu = frt.CameraUniform()
+        col = lambda m: np.asarray(m, np.float32).T.reshape(16)      # row-major math -> column-major storage
+        cu.view_proj[:] = col(vp); cu.view_inverse[:] = col(np.linalg.inv(view)); cu.proj_inverse[:] = col(np.linalg.inv(proj))
+        cu.prev_view_proj[:] = col(prev_vp if prev_vp is not None else vp)
+        cu.view_pos[:] = [eye[0], eye[1], eye[2], 1.0]
+        cu.frame_count, cu.num_lights = f, num_lights
+        out.append(cu)
+        prev_vp = vp
+    return out

@@ -175,3 +175,17 @@ def test_two_rank_strips_through_torch_distributed(gpu, tmp_path):
     res = run_ranks("gpu", 2, tmp_path, ("--H", "128", "--W", "160", "--frames", "4", "--balanced", "1"))
     assert res["ok"] and res["rays_all_ranks"] == res["oracle_rays"], res
     assert res["bounds"][1] != 64, res
+
+
+def test_moving_camera_on_gpu(gpu, orc):
+    frt = gpu
+    import _scenes
+    fs = frt.scenes.create_cornell_box(); os_ = orc.cornell()
+    os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    W, H = 192, 128
+    cams = _scenes.moving_camera_uniforms(frt, W / H, 2, 6)
+    r = frt.Renderer(fs, W, H); ro = os_.renderer(W, H, 8, True, 16)
+    for f, cam in enumerate(cams):
+        r.render(cam); ro.render(cam)
+        compare_all(r.read_buffer, ro.read, f, "moving camera")
+    assert np.abs(r.read_buffer(frt.BUF_GMOTION, 0).view(np.float32)).max() > 1e-3

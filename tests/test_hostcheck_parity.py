@@ -36,3 +36,21 @@ def test_stage_functions_match_oracle(frt, orc, hostcheck, which, size, depth, f
     st = ro.stats()["total"]
     assert rh.rays() == (st["closest"], st["any"])
     assert st["closest"] + st["any"] <= (4 + 2 * (2 * depth - 1)) * W * H * frames    # SURVEY §8(a) ray budget: 36 at MAX_DEPTH 8
+
+
+def test_moving_camera_matches_oracle(frt, orc, hostcheck):
+    """Moving camera: motion vectors != 0, temporal reprojection lands on other pixels, post takes the TAA clamp branch
+    (gbuffer.wgsl:230-242, restir.wgsl:846-900, post.wgsl:187-266). Same CameraUniform bytes to both sides."""
+    import _scenes
+    fs = frt.scenes.create_cornell_box(); os_ = orc.cornell()
+    os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    W, H = 96, 64
+    cams = _scenes.moving_camera_uniforms(frt, W / H, 2, 5)
+    ro = os_.renderer(W, H, 8, True, 8); rh = hostcheck.renderer(fs, W, H, 8, 8)
+    for f, cam in enumerate(cams):
+        ro.render(cam); rh.render(cam)
+        compare_all(rh.read, ro.read, f, "moving camera")
+    mot = ro.read(3, 0).view(np.float32)
+    assert np.abs(mot).max() > 1e-3                       # the motion path really is exercised
+    res_t = ro.read(4, 0).view(np.uint32)
+    assert (res_t[..., 2] > 1).any()                      # and temporal reuse still merges some reprojected reservoirs
