@@ -119,7 +119,7 @@ def main():
     stream = torch.cuda.current_stream()
     r = frt.Renderer(scene, W, H, max_depth=MAX_DEPTH, device=local_rank, stream=stream.cuda_stream,
                      rows=(plan.row_begin, plan.row_end) if world > 1 else None,
-                     arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_TIMING)
+                     arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_TIMING | frt.FLAG_OVERLAP_POST)
     rows = ArenaRows(r, arena)
 
     def frame(f):

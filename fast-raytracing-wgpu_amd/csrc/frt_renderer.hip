@@ -30,13 +30,16 @@ static_assert(sizeof(PairNode) == 64 && sizeof(TriSlot) == 48 && sizeof(ShadeTri
 static const uint32_t kHaloGbuffer = 12;   // spatial reuse radius 10 (restir_spatial.wgsl:903, :921) + spatial halo 2
 static const uint32_t kHaloSpatial = 2;    // post reads raw radiance within +-2 rows (post.wgsl:93)
 
-enum { B_GPOS0, B_GPOS1, B_GNRM0, B_GNRM1, B_GALB0, B_GALB1, B_GMOT, B_RES0, B_RES1, B_RAW, B_DISP, B_ACC0, B_ACC1, B_COUNT };
-static const uint32_t kBpp[B_COUNT] = {16, 16, 16, 16, 4, 4, 8, 32, 32, 8, 4, 16, 16};
+enum { B_GPOS0, B_GPOS1, B_GNRM0, B_GNRM1, B_GALB0, B_GALB1, B_GMOT, B_RES0, B_RES1, B_RAW, B_DISP, B_ACC0, B_ACC1, B_GMOT1, B_COUNT };
+static const uint32_t kBpp[B_COUNT] = {16, 16, 16, 16, 4, 4, 8, 32, 32, 8, 4, 16, 16, 8};
 
 struct frt_renderer {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t side = nullptr;            // FRT_FLAG_OVERLAP_POST: the post stage runs here
+    hipEvent_t ev_spatial = nullptr, ev_post = nullptr;
+    bool post_in_flight = false;
     uint32_t W = 0, H = 0, max_depth = 8, rb = 0, re = 0, flags = 0;
     uint32_t frame_count = 0;
     SceneView sv{};
@@ -119,7 +122,7 @@ static void fill_frame_view(const frt_renderer* r, const frt_camera_uniform* cam
     fv.gpos = (float4*)r->buf(B_GPOS0 + cur); fv.gnormal = (float4*)r->buf(B_GNRM0 + cur); fv.galbedo = (uint32_t*)r->buf(B_GALB0 + cur);
     fv.gpos_prev = (const float4*)r->buf(B_GPOS0 + prv); fv.gnormal_prev = (const float4*)r->buf(B_GNRM0 + prv);
     fv.galbedo_prev = (const uint32_t*)r->buf(B_GALB0 + prv);
-    fv.gmotion = (float2*)r->buf(B_GMOT);
+    fv.gmotion = (float2*)r->buf((r->side && cur) ? B_GMOT1 : B_GMOT);   // ping-pong only when post overlaps the next G-buffer
     fv.res_temporal = (ReservoirView*)r->buf(B_RES0);   // restir.rs:362-378: reads buffers[1], writes buffers[0]
     fv.res_spatial = (ReservoirView*)r->buf(B_RES1);    // renderer.rs:292-293: spatial buffers[0] -> buffers[1]
     fv.raw = (uint2*)r->buf(B_RAW); fv.display = (uint32_t*)r->buf(B_DISP);
@@ -129,6 +132,12 @@ static void fill_frame_view(const frt_renderer* r, const frt_camera_uniform* cam
     fv.W = r->W; fv.H = r->H; fv.frame_count = r->frame_count; fv.max_depth = r->max_depth;
     fv.own_y0 = r->rb; fv.own_y1 = r->re;
     memcpy(&fv.cam, cam, sizeof(CameraView));
+}
+
+static int sync_all(frt_renderer* r) {
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (r->side) HIP_TRY(hipStreamSynchronize(r->side));
+    return FRT_OK;
 }
 
 static int resolve_timing(frt_renderer* r) {
@@ -293,6 +302,9 @@ void frt_renderer_destroy(frt_renderer* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     (void)hipStreamSynchronize(r->stream);
+    if (r->side) { (void)hipStreamSynchronize(r->side); (void)hipStreamDestroy(r->side); }
+    if (r->ev_spatial) (void)hipEventDestroy(r->ev_spatial);
+    if (r->ev_post) (void)hipEventDestroy(r->ev_post);
     for (auto& t : r->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (void* p : r->scene_allocs) (void)hipFree(p);
     if (r->own_arena && r->arena) (void)hipFree(r->arena);
@@ -311,6 +323,11 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     HIP_TRY(hipSetDevice(r->device));
     if (o && (o->stream || (o->flags & FRT_FLAG_USE_STREAM))) { r->stream = (hipStream_t)o->stream; r->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); r->own_stream = true; }
+    if (r->flags & FRT_FLAG_OVERLAP_POST) {
+        HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_spatial, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_post, hipEventDisableTiming));
+    }
     r->arena_bytes = arena_layout(r->W, r->H, r->off);
     if (o && o->device_arena) {
         if (o->arena_bytes < r->arena_bytes) return fail(FRT_ERR_INVALID_ARG, "device_arena smaller than frt_renderer_arena_bytes");
@@ -374,11 +391,21 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
         if (!(phases & (1 << stage))) continue;
         fv.y0 = rows[2 * stage]; fv.y1 = rows[2 * stage + 1];
         fv.ray_counters = r->d_counters + 2 * stage;
+        hipStream_t q = r->stream;
+        if (r->side && stage == 3) {   // post(f) on the side stream, after spatial(f)
+            HIP_TRY(hipEventRecord(r->ev_spatial, r->stream));
+            HIP_TRY(hipStreamWaitEvent(r->side, r->ev_spatial, 0));
+            q = r->side;
+        }
+        if (r->side && stage == 2 && r->post_in_flight) {   // spatial(f+1) overwrites the radiance post(f) reads
+            HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0));
+            r->post_in_flight = false;
+        }
         frt_renderer::Timed t{};
         bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
         if (timed) {
             HIP_TRY(hipEventCreate(&t.a)); HIP_TRY(hipEventCreate(&t.b)); t.stage = stage;
-            HIP_TRY(hipEventRecord(t.a, r->stream));
+            HIP_TRY(hipEventRecord(t.a, q));
         }
         StageLaunch L{};
         L.compaction = (r->flags & FRT_FLAG_COMPACTION) != 0;
@@ -392,8 +419,15 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
                 L.queues[k].capacity = (uint32_t)npix;
             }
         }
-        HIP_TRY(launch_stage(stage, r->sv, fv, r->stream, L));
-        if (timed) { HIP_TRY(hipEventRecord(t.b, r->stream)); r->pending.push_back(t); }
+        HIP_TRY(launch_stage(stage, r->sv, fv, q, L));
+        if (timed) { HIP_TRY(hipEventRecord(t.b, q)); r->pending.push_back(t); }
+        if (r->side && stage == 3) { HIP_TRY(hipEventRecord(r->ev_post, r->side)); r->post_in_flight = true; }
+        if (r->side && stage == 1 && r->post_in_flight) {
+            // temporal(f+1) may overlap post(f); whatever the caller enqueues next on the main stream (the halo exchange of the
+            // previous accumulation rows, then spatial) must see post(f) finished
+            HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0));
+            r->post_in_flight = false;
+        }
         r->stats.launches[stage] += 1;
     }
     return FRT_OK;
@@ -412,8 +446,7 @@ int frt_renderer_render(frt_renderer* r, const frt_camera_uniform* cam) {
 int frt_renderer_sync(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "sync: null");
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    return FRT_OK;
+    return sync_all(r);
 }
 uint32_t frt_renderer_frame_count(const frt_renderer* r) { return r ? r->frame_count : 0u; }
 int frt_renderer_reset(frt_renderer* r) {
@@ -424,7 +457,7 @@ int frt_renderer_reset(frt_renderer* r) {
 int frt_renderer_clear(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "clear: null");
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    { int rc_ = sync_all(r); if (rc_) return rc_; }
     int rc = resolve_timing(r);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));
@@ -440,7 +473,7 @@ static int buf_index(int buf, int index) {
     case FRT_BUF_GPOS: return B_GPOS0 + (index & 1);
     case FRT_BUF_GNORMAL: return B_GNRM0 + (index & 1);
     case FRT_BUF_GALBEDO: return B_GALB0 + (index & 1);
-    case FRT_BUF_GMOTION: return B_GMOT;
+    case FRT_BUF_GMOTION: return (index & 1) ? B_GMOT1 : B_GMOT;
     case FRT_BUF_RESERVOIR: return B_RES0 + (index & 1);
     case FRT_BUF_RAW: return B_RAW;
     case FRT_BUF_DISPLAY: return B_DISP;
@@ -459,7 +492,7 @@ int frt_renderer_read_buffer(frt_renderer* r, int buf, int index, void* out) {
     int b = r ? buf_index(buf, index) : -1;
     if (b < 0 || !out) return fail(FRT_ERR_INVALID_ARG, "read_buffer: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    { int rc_ = sync_all(r); if (rc_) return rc_; }
     HIP_TRY(hipMemcpy(out, r->buf(b), (size_t)r->W * r->H * kBpp[b], hipMemcpyDeviceToHost));
     return FRT_OK;
 }
@@ -467,7 +500,7 @@ int frt_renderer_read_rows(frt_renderer* r, int buf, int index, uint32_t y0, uin
     int b = r ? buf_index(buf, index) : -1;
     if (b < 0 || !out || y0 > y1 || y1 > r->H) return fail(FRT_ERR_INVALID_ARG, "read_rows: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    { int rc_ = sync_all(r); if (rc_) return rc_; }
     size_t pitch = (size_t)r->W * kBpp[b];
     HIP_TRY(hipMemcpy(out, (uint8_t*)r->buf(b) + pitch * y0, pitch * (y1 - y0), hipMemcpyDeviceToHost));
     return FRT_OK;
@@ -476,7 +509,7 @@ int frt_renderer_write_rows(frt_renderer* r, int buf, int index, uint32_t y0, ui
     int b = r ? buf_index(buf, index) : -1;
     if (b < 0 || !in || y0 > y1 || y1 > r->H) return fail(FRT_ERR_INVALID_ARG, "write_rows: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    { int rc_ = sync_all(r); if (rc_) return rc_; }
     size_t pitch = (size_t)r->W * kBpp[b];
     HIP_TRY(hipMemcpy((uint8_t*)r->buf(b) + pitch * y0, in, pitch * (y1 - y0), hipMemcpyHostToDevice));
     return FRT_OK;
@@ -495,7 +528,7 @@ int frt_renderer_phase_rows(const frt_renderer* r, uint32_t out[8]) {
 int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
     if (!r || !out) return fail(FRT_ERR_INVALID_ARG, "stats: null");
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    { int rc_ = sync_all(r); if (rc_) return rc_; }
     int rc = resolve_timing(r);
     if (rc) return rc;
     unsigned long long c[8] = {0};

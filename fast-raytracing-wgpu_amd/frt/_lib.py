@@ -46,6 +46,7 @@ assert C.sizeof(VertexAttr) == 32 and C.sizeof(Material) == 64 and C.sizeof(Ligh
 FLAG_TIMING = 1
 FLAG_COMPACTION = 2
 FLAG_USE_STREAM = 4
+FLAG_OVERLAP_POST = 8
 PHASE_GBUFFER, PHASE_TEMPORAL, PHASE_SPATIAL, PHASE_POST, PHASE_ALL = 1, 2, 4, 8, 15
 BUF_GPOS, BUF_GNORMAL, BUF_GALBEDO, BUF_GMOTION, BUF_RESERVOIR, BUF_RAW, BUF_DISPLAY, BUF_ACCUM = range(8)
 BUF_BPP = {BUF_GPOS: 16, BUF_GNORMAL: 16, BUF_GALBEDO: 4, BUF_GMOTION: 8, BUF_RESERVOIR: 32, BUF_RAW: 8, BUF_DISPLAY: 4, BUF_ACCUM: 16}

@@ -131,6 +131,8 @@ typedef struct frt_render_opts {
     uint32_t reserved;
 } frt_render_opts;
 #define FRT_FLAG_TIMING 1u          /* record per-stage HIP events every frame (frt_stats.ms_*) */
+#define FRT_FLAG_OVERLAP_POST 8u    /* run the post stage of frame f on a second stream, concurrently with G-buffer + temporal of frame f+1
+                                       (post is off the T -> S -> T critical path; matters for thin strips / many GPUs) */
 #define FRT_FLAG_USE_STREAM 4u      /* opts->stream is authoritative even when NULL (= the legacy default stream, e.g. torch's current stream) */
 #define FRT_FLAG_COMPACTION 2u      /* temporal / spatial stages through the workgroup-compacting kernels (opt-in: measured slower than
                                        one thread per pixel on the Cornell Box, profiles/r1_v3_*; same pixels either way) */
@@ -142,7 +144,7 @@ enum {
     FRT_BUF_GPOS = 0,        /* rgba32f  16 B/px, x2 ping-pong */
     FRT_BUF_GNORMAL = 1,     /* rgba32f  16 B/px, x2 */
     FRT_BUF_GALBEDO = 2,     /* rgba8    4 B/px, x2 */
-    FRT_BUF_GMOTION = 3,     /* rg32f    8 B/px */
+    FRT_BUF_GMOTION = 3,     /* rg32f    8 B/px (slot 0; x2 ping-pong under FRT_FLAG_OVERLAP_POST) */
     FRT_BUF_RESERVOIR = 4,   /* 32 B/px, [0] temporal result, [1] spatial result */
     FRT_BUF_RAW = 5,         /* rgba16f  8 B/px */
     FRT_BUF_DISPLAY = 6,     /* rgba8    4 B/px */

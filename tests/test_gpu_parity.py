@@ -189,3 +189,32 @@ def test_moving_camera_on_gpu(gpu, orc):
         r.render(cam); ro.render(cam)
         compare_all(r.read_buffer, ro.read, f, "moving camera")
     assert np.abs(r.read_buffer(frt.BUF_GMOTION, 0).view(np.float32)).max() > 1e-3
+
+
+def test_post_overlap_flag_gives_identical_frames(gpu, orc):
+    """FRT_FLAG_OVERLAP_POST: post(f) on a second stream concurrently with G-buffer + temporal of frame f+1 — same pixels, also for
+    strips with the halo exchange in between."""
+    frt = gpu
+    from frt.dist import StripPlan, exchange_halos_host
+    W, H, N = 256, 160, 7
+    fs = frt.scenes.create_cornell_box()
+    os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    ro = os_.renderer(W, H, 8, True, 16)
+    r = frt.Renderer(fs, W, H, flags=frt.FLAG_OVERLAP_POST)
+    plans = [StripPlan(H, 2, k) for k in range(2)]
+    strips = [frt.Renderer(fs, W, H, rows=(p.row_begin, p.row_end), flags=frt.FLAG_OVERLAP_POST) for p in plans]
+    for f in range(N):
+        cam = frt.CameraController().build_uniform(W / H, f, 2)
+        ro.render(cam); r.render(cam)                      # no sync between frames: post(f) really overlaps frame f+1
+        for s in strips:
+            s.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
+        exchange_halos_host(strips, plans, f)
+        for s in strips:
+            s.render_phases(cam, frt.PHASE_SPATIAL | frt.PHASE_POST); s.end_frame()
+    last = (N - 1) % 2
+    for b, idx in ((0, last), (1, last), (2, last), (4, 0), (4, 1), (5, 0), (6, 0), (7, last), (7, last ^ 1)):
+        assert r.read_buffer(b, idx).tobytes() == ro.read(b, idx).tobytes(), (b, idx)
+    assert r.read_buffer(frt.BUF_GMOTION, last).tobytes() == ro.read(3, 0).tobytes()
+    want = ro.read(7, last)
+    for s, p in zip(strips, plans):
+        assert s.read_buffer(7, last)[p.row_begin:p.row_end].tobytes() == want[p.row_begin:p.row_end].tobytes()

@@ -6,13 +6,12 @@ import frt
 W, H = 1920, 1080
 scene = frt.scenes.create_cornell_box()
 cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(40)]
-for cuts in ("4", "0"):
-    os.environ["FRT_CUTS"] = cuts
-    for world in (1, 2, 4, 8):
+for cuts, extra in (("default", 0), ("default+overlap_post", frt.FLAG_OVERLAP_POST)):
+    for world in (2, 4, 8):
         worst = 0
         for rank in range(world):
             rb, re = H * rank // world, H * (rank + 1) // world
-            r = frt.Renderer(scene, W, H, rows=(rb, re) if world > 1 else None, flags=frt.FLAG_TIMING)
+            r = frt.Renderer(scene, W, H, rows=(rb, re) if world > 1 else None, flags=frt.FLAG_TIMING | extra)
             for f in range(8):
                 r.render(cams[f])
             r.sync(); s0 = r.stats(); t0 = time.perf_counter()
@@ -21,7 +20,7 @@ for cuts in ("4", "0"):
             r.sync(); dt = (time.perf_counter() - t0) / 32 * 1e3; s1 = r.stats()
             ms = [(a - b) / 32 for a, b in zip(s1["ms_stage"], s0["ms_stage"])]
             worst = max(worst, dt)
-            if world == 8 or rank == 0:
+            if rank == 0:
                 print(f"cuts={cuts} world {world} rank {rank}: {dt:.3f} ms/frame stages " + " ".join(f"{m:.3f}" for m in ms), flush=True)
             del r
         print(f"cuts={cuts} world {world}: slowest strip {worst:.3f} ms -> ideal-exchange speedup bound")
