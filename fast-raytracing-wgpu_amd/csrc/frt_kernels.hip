@@ -292,9 +292,52 @@ __global__ void __launch_bounds__(kBlock, 4) continue_kernel(SceneView sc, Frame
     flush_ray_counters(fv, owned ? c.n_closest : 0u, owned ? c.n_any : 0u, s_cnt);
 }
 
+// Post / accumulate: a 5x5 bilateral + 3x3 variance stencil (post.wgsl:95-170). The 16x16 pixel workgroup first stages its
+// 20x20 neighbourhood in LDS as DECODED values (f16 radiance -> f32, unorm8 albedo -> f32, octahedral normal -> unit vector,
+// position): 12 floats per entry, SoA with a row pitch of 24 words so that the 8x8 tile a wave reads maps to 32 distinct banks.
+// Each entry is decoded once per workgroup instead of once per tap (25x fewer normalisations and unorm divisions), and the
+// taps become ds_read_b32 instead of four global loads.
+static constexpr int kTileW = 20, kTilePitch = 24, kTileH = 20, kTileN = kTilePitch * kTileH;
+struct TileTaps {
+    const float* t;   // [12][kTileN] in LDS
+    int ox, oy;       // image coordinates of tile entry (0, 0)
+    __device__ __forceinline__ int at(int nx, int ny) const { return (ny - oy) * kTilePitch + (nx - ox); }
+    __device__ __forceinline__ TapData get(int nx, int ny) const {
+        const int i = at(nx, ny);
+        TapData d;
+        d.color = mk3(t[0 * kTileN + i], t[1 * kTileN + i], t[2 * kTileN + i]);
+        d.albedo = mk3(t[3 * kTileN + i], t[4 * kTileN + i], t[5 * kTileN + i]);
+        d.normal = mk3(t[6 * kTileN + i], t[7 * kTileN + i], t[8 * kTileN + i]);
+        d.pos = mk3(t[9 * kTileN + i], t[10 * kTileN + i], t[11 * kTileN + i]);
+        return d;
+    }
+    __device__ __forceinline__ f3 color(int nx, int ny) const {
+        const int i = at(nx, ny);
+        return mk3(t[0 * kTileN + i], t[1 * kTileN + i], t[2 * kTileN + i]);
+    }
+};
+
 __global__ void __launch_bounds__(kBlock) post_kernel(FrameView fv) {
+    __shared__ float s_tile[12 * kTileN];
+    const int ox = (int)(blockIdx.x * 16u) - 2, oy = (int)(fv.y0 + blockIdx.y * 16u) - 2;
+    for (int e = (int)threadIdx.x; e < kTileW * kTileH; e += kBlock) {
+        const int tx = e % kTileW, ty = e / kTileW;
+        const int nx = ox + tx, ny = oy + ty;
+        if (nx >= 0 && ny >= 0 && nx < (int)fv.W && ny < (int)fv.H) {
+            const TapData d = decode_tap(fv, (uint32_t)ny * fv.W + (uint32_t)nx);
+            const int i = ty * kTilePitch + tx;
+            s_tile[0 * kTileN + i] = d.color.x; s_tile[1 * kTileN + i] = d.color.y; s_tile[2 * kTileN + i] = d.color.z;
+            s_tile[3 * kTileN + i] = d.albedo.x; s_tile[4 * kTileN + i] = d.albedo.y; s_tile[5 * kTileN + i] = d.albedo.z;
+            s_tile[6 * kTileN + i] = d.normal.x; s_tile[7 * kTileN + i] = d.normal.y; s_tile[8 * kTileN + i] = d.normal.z;
+            s_tile[9 * kTileN + i] = d.pos.x; s_tile[10 * kTileN + i] = d.pos.y; s_tile[11 * kTileN + i] = d.pos.z;
+        }
+    }
+    __syncthreads();
     uint32_t px, py;
-    if (tile_pixel(fv, px, py)) post_pixel(fv, px, py);
+    if (tile_pixel(fv, px, py)) {
+        TileTaps taps{s_tile, ox, oy};
+        post_pixel_t(fv, px, py, taps);
+    }
 }
 
 static dim3 grid_for(const FrameView& fv) { return dim3((fv.W + 15u) / 16u, (fv.y1 - fv.y0 + 15u) / 16u, 1u); }

@@ -360,7 +360,7 @@ FRT_HD void gbuffer_pixel(PathCtx& c, uint32_t px, uint32_t py) {
 // ================================================================================================ stage 3
 // post.wgsl:61-282. jitter == 0 (camera.rs:202-203): textureSampleLevel(raw_tex / albedo_tex) lands on texel centres -> texel fetch.
 FRT_HD float gauss(float x, float sigma) {   // post.wgsl:21-26 (sigma >= 0.001 at every call site)
-    return expf_(-(x * x) / (2.0f * sigma * sigma));
+    return expf_(-(x * x) * (1.0f / (2.0f * sigma * sigma)));   // x / c evaluated as x * (1 / c) (contract); sigma is a constant
 }
 FRT_HD f3 rgb_to_ycocg(f3 c) {
     return mk3(c.x * 0.25f + c.y * 0.5f + c.z * 0.25f, c.x * 0.5f + c.y * 0.0f + c.z * -0.5f, c.x * -0.25f + c.y * 0.5f + c.z * -0.25f);
@@ -369,35 +369,46 @@ FRT_HD f3 ycocg_to_rgb(f3 c) { return mk3(c.x + c.y - c.z, c.x + c.z, c.x - c.y 
 FRT_HD f3 resolve_tonemap(f3 c) { return c / (1.0f + fmaxn(c.x, fmaxn(c.y, c.z))); }
 FRT_HD f3 resolve_inverse_tonemap(f3 c) { return c / (1.0f - fmaxn(c.x, fmaxn(c.y, c.z))); }
 
-FRT_HD void post_pixel(const FrameView& fv, uint32_t px, uint32_t py) {
+// What the 5x5 bilateral and 3x3 variance loops read of a neighbour pixel. GlobalTaps decodes it from the per-pixel buffers in
+// HBM on every tap (host check, reference form); the post kernel stages a 20x20 tile of already decoded values in LDS instead
+// (frt_kernels.hip: TileTaps), so each pixel is decoded once per workgroup rather than 25 times. Same functions, same values.
+struct TapData { f3 color, albedo, normal, pos; };
+FRT_HD TapData decode_tap(const FrameView& fv, uint32_t nidx) {
+    TapData t;
+    t.color = xyz(unpack_rgba16f(fv.raw[nidx]));
+    t.albedo = xyz(unpack_rgba8(fv.galbedo[nidx]));
+    float4 sn = fv.gnormal[nidx];
+    t.normal = decode_octahedral_normal(sn.x, sn.y);
+    float4 sp4 = fv.gpos[nidx];
+    t.pos = mk3(sp4.x, sp4.y, sp4.z);
+    return t;
+}
+struct GlobalTaps {
+    const FrameView& fv;
+    FRT_HD TapData get(int nx, int ny) const { return decode_tap(fv, (uint32_t)ny * fv.W + (uint32_t)nx); }
+    FRT_HD f3 color(int nx, int ny) const { return xyz(unpack_rgba16f(fv.raw[(uint32_t)ny * fv.W + (uint32_t)nx])); }
+};
+
+template <class Taps>
+FRT_HD void post_pixel_t(const FrameView& fv, uint32_t px, uint32_t py, const Taps& taps) {
     int W = (int)fv.W, H = (int)fv.H;
     uint32_t idx = py * fv.W + px;
-    f3 center_color = xyz(unpack_rgba16f(fv.raw[idx]));
-    f3 center_albedo = xyz(unpack_rgba8(fv.galbedo[idx]));
-    float4 cn = fv.gnormal[idx];
-    f3 center_normal = decode_octahedral_normal(cn.x, cn.y);
-    float4 cp4 = fv.gpos[idx];
-    f3 center_pos = mk3(cp4.x, cp4.y, cp4.z);
+    const TapData ctr = taps.get((int)px, (int)py);
+    f3 center_color = ctr.color, center_albedo = ctr.albedo, center_normal = ctr.normal, center_pos = ctr.pos;
     f3 sum_color = splat3(0.0f);
     float sum_weight = 0.0f;
     for (int dy = -2; dy <= 2; dy++) {
         for (int dx = -2; dx <= 2; dx++) {
             int nx = (int)px + dx, ny = (int)py + dy;
             if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
-            uint32_t nidx = (uint32_t)ny * fv.W + (uint32_t)nx;
-            f3 sample_color = xyz(unpack_rgba16f(fv.raw[nidx]));
-            f3 sample_albedo = xyz(unpack_rgba8(fv.galbedo[nidx]));
-            float4 sn = fv.gnormal[nidx];
-            f3 sample_normal = decode_octahedral_normal(sn.x, sn.y);
-            float4 sp4 = fv.gpos[nidx];
-            f3 sample_pos = mk3(sp4.x, sp4.y, sp4.z);
+            const TapData t = taps.get(nx, ny);
             float w_spatial = gauss(length2(mk2((float)dx, (float)dy)), 1.5f);
-            float w_color = gauss(length(sample_albedo - center_albedo), 0.2f);
-            float dot_normal = clampf(dot(center_normal, sample_normal), 0.0f, 1.0f);
+            float w_color = gauss(length(t.albedo - center_albedo), 0.2f);
+            float dot_normal = clampf(dot(center_normal, t.normal), 0.0f, 1.0f);
             float w_normal = pow20_(dot_normal);
-            float w_pos = gauss(length(sample_pos - center_pos), 0.1f);
+            float w_pos = gauss(length(t.pos - center_pos), 0.1f);
             float weight = w_spatial * w_color * w_normal * w_pos;
-            sum_color = sum_color + sample_color * weight;
+            sum_color = sum_color + t.color * weight;
             sum_weight += weight;
         }
     }
@@ -409,7 +420,7 @@ FRT_HD void post_pixel(const FrameView& fv, uint32_t px, uint32_t py) {
         for (int dx = -1; dx <= 1; dx++) {
             int nx = (int)px + dx, ny = (int)py + dy;
             f3 s_col = filtered_color;
-            if (nx >= 0 && ny >= 0 && nx < W && ny < H) s_col = xyz(unpack_rgba16f(fv.raw[(uint32_t)ny * fv.W + (uint32_t)nx]));
+            if (nx >= 0 && ny >= 0 && nx < W && ny < H) s_col = taps.color(nx, ny);
             f3 s_ycocg = rgb_to_ycocg(resolve_tonemap(s_col));
             m1 = m1 + s_ycocg;
             m2 = m2 + s_ycocg * s_ycocg;
@@ -467,5 +478,6 @@ FRT_HD void post_pixel(const FrameView& fv, uint32_t px, uint32_t py) {
     const float inv_gamma = (float)(1.0 / 2.2);
     fv.display[idx] = pack_rgba8(mk4(powf_(final_color.x, inv_gamma), powf_(final_color.y, inv_gamma), powf_(final_color.z, inv_gamma), 1.0f));
 }
+FRT_HD void post_pixel(const FrameView& fv, uint32_t px, uint32_t py) { GlobalTaps taps{fv}; post_pixel_t(fv, px, py, taps); }
 
 } // namespace frt

@@ -775,7 +775,7 @@ static void spatial_pixel(Ctx& c, Renderer& R, uint32_t px, uint32_t py) {
 // ------------------------------------------------------------------ stage 3: post.wgsl:61-282
 static float gauss(float x, float sigma) {   // post.wgsl:21-26
     if (sigma < 0.001f) return fabsf(x) < 0.001f ? 1.0f : 0.0f;
-    return exp_(-(x * x) / (2.0f * sigma * sigma));
+    return exp_(-(x * x) * (1.0f / (2.0f * sigma * sigma)));   // x / c evaluated as x * (1 / c) (contract)
 }
 static vec3 rgb_to_ycocg(vec3 rgb) {
     return V3(rgb.x * 0.25f + rgb.y * 0.5f + rgb.z * 0.25f, rgb.x * 0.5f + rgb.y * 0.0f + rgb.z * -0.5f,

@@ -6,7 +6,7 @@ import frt
 W, H = 1920, 1080
 scene = frt.scenes.create_cornell_box()
 cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(40)]
-rs = {"plain": frt.Renderer(scene, W, H, flags=frt.FLAG_TIMING), "overlap_post": frt.Renderer(scene, W, H, flags=frt.FLAG_TIMING | frt.FLAG_OVERLAP_POST)}
+rs = {"default": frt.Renderer(scene, W, H, flags=frt.FLAG_TIMING)}
 for rnd in range(2):
     for k, r in rs.items():
         r.clear()
