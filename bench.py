@@ -111,7 +111,12 @@ def main():
     cams = [cam_ctl.build_uniform(W / H, f, nl) for f in range(max(total, a.cpu_frames + 1))]
 
     # strips of equal WORK (probe render, identical on every rank), not equal height
-    bounds = balanced_boundaries(frt, scene, W, H, world, max_depth=MAX_DEPTH, device=local_rank) if world > 1 else None
+    bounds = None
+    if world > 1:
+        try:
+            bounds = balanced_boundaries(frt, scene, W, H, world, max_depth=MAX_DEPTH, device=local_rank)
+        except Exception as e:      # equal strips are always valid; balancing is an optimisation
+            print(f"[rank {rank}] work-balanced strips unavailable ({e}); using equal strips", file=sys.stderr)
     plan = StripPlan(H, world, rank, bounds)
     nbytes = frt.Renderer.arena_bytes(W, H)
     arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device=f"cuda:{local_rank}")
