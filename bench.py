@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (N = 1 only; 0 disables)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1. nccl (= RCCL over xGMI) is the real thing; gloo stages the halo rows through the "
+                         "host and lets several ranks share ONE GPU (set FRT_BENCH_ONE_GPU=1) to rehearse the N > 1 code path on a 1-GPU box")
     a = ap.parse_args()
 
     import torch
@@ -97,11 +100,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch N > 1 with torch.distributed.run")
+    if os.environ.get("FRT_BENCH_ONE_GPU") == "1":
+        local_rank = 0                        # rehearsal: every rank renders on cuda:0 (gloo only)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm_dev = f"cuda:{local_rank}" if a.backend == "nccl" else "cpu"
 
     from frt.dist import StripPlan, ArenaRows, exchange_halos, balanced_boundaries
     scene = frt.scenes.create_cornell_box()
@@ -125,7 +134,7 @@ def main():
     r = frt.Renderer(scene, W, H, max_depth=MAX_DEPTH, device=local_rank, stream=stream.cuda_stream,
                      rows=(plan.row_begin, plan.row_end) if world > 1 else None,
                      arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_TIMING | frt.FLAG_OVERLAP_POST)
-    rows = ArenaRows(r, arena)
+    rows = ArenaRows(r, arena, staging_device=None if a.backend == "nccl" else "cpu")
 
     def frame(f):
         if world == 1:
@@ -155,10 +164,10 @@ def main():
 
     rays = (s1["rays_closest"] + s1["rays_any"]) - (s0["rays_closest"] + s0["rays_any"])
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        n = torch.tensor([rays], dtype=torch.int64, device=f"cuda:{local_rank}")
+        n = torch.tensor([rays], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
         rays = int(n.item())
 
@@ -186,7 +195,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell Box 1920x1080, MAX_DEPTH 8, 1 candidate path/pixel/frame, 4-stage ReSTIR-PT frame (BASELINE.json configs[1])",
-                       "rays_per_frame": rays / a.steps, "parallelism": "1 GPU" if world == 1 else f"{world} work-balanced image strips {bounds}, 1 halo exchange/frame (RCCL)"},
+                       "rays_per_frame": rays / a.steps, "parallelism": "1 GPU" if world == 1 else f"{world} work-balanced image strips {bounds}, 1 halo exchange/frame ({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'})"},
             "roofline": {"bound": "hbm", "kernel": {0: "gbuffer_kernel", 1: "temporal stage = pixel_kernel<1> + continue_kernel<1>", 2: "spatial + shade stage = pixel_kernel<2> + continue_kernel<2>", 3: "post_kernel"}[dom], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(name) if world == 1 else None,
                          "avg_launch_ms": ms[dom], "launches_per_step": 2 if dom in (1, 2) else 1, "algorithmic_bytes_per_launch": algo_bytes,
