@@ -18,13 +18,14 @@ class Renderer:
             o.device_arena, o.arena_bytes = arena, arena_bytes
         self.width, self.height = width, height
         self._scene = scene     # keep the scene alive
+        self._destroy = lib().frt_renderer_destroy
         self._h = lib().frt_renderer_create(scene._h, width, height, C.byref(o))
         if not self._h:
             raise FrtError("renderer creation failed: " + lib().frt_last_error().decode())
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().frt_renderer_destroy(self._h)
+            self._destroy(self._h)     # bound at construction: module globals may already be gone at interpreter exit
             self._h = None
 
     @staticmethod

@@ -14,13 +14,14 @@ def material_new(base_color):
 
 class SceneBuilder:
     def __init__(self, handle=None):
+        self._destroy = lib().frt_scene_destroy
         self._h = handle if handle is not None else lib().frt_scene_create()
         if not self._h:
             raise FrtError("scene creation failed: " + lib().frt_last_error().decode())
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().frt_scene_destroy(self._h)
+            self._destroy(self._h)     # bound at construction: module globals may already be gone at interpreter exit
             self._h = None
 
     # builder.rs:123
