@@ -14,6 +14,7 @@ using namespace frt;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+namespace frt { int set_error(int code, const std::string& msg) { return fail(code, msg); } }   // for the other translation units of the ABI
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \

@@ -73,6 +73,19 @@ SYMBOLS = {
     "frt_scene_build": (C.c_int, [_P]),
     "frt_scene_create_cornell_box": (_P, []),
     "frt_scene_create_restir_scene": (_P, []),
+    "frt_model_load": (_P, [C.c_char_p]),
+    "frt_model_destroy": (None, [_P]),
+    "frt_model_counts": (C.c_int, [_P, _P]),
+    "frt_model_geometry_counts": (C.c_int, [_P, _U32, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
+    "frt_model_geometry_get": (C.c_int, [_P, _U32, _P, _P, _P]),
+    "frt_model_material_get": (C.c_int, [_P, _U32, C.POINTER(Material)]),
+    "frt_model_material_set": (C.c_int, [_P, _U32, C.POINTER(Material)]),
+    "frt_model_image_get": (C.c_int, [_P, _U32, _P]),
+    "frt_model_warning": (C.c_char_p, [_P, _U32]),
+    "frt_scene_add_gltf_materials": (C.c_int, [_P, _P, _P]),
+    "frt_scene_add_gltf_meshes": (C.c_int, [_P, _P, _P]),
+    "frt_scene_add_gltf_instances": (C.c_int, [_P, _P, _P, _U32, _P, _U32, _P]),
+    "frt_scene_create_gltf_scene": (_P, [C.c_char_p, _P, _P]),
     "frt_scene_counts": (C.c_int, [_P, _P]),
     "frt_scene_get": (C.c_int, [_P, C.c_int, _P]),
     "frt_scene_bvh_stats": (C.c_int, [_P, _P]),

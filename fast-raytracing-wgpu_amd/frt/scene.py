@@ -63,6 +63,22 @@ class SceneBuilder:
         t = np.ascontiguousarray(rgba8, np.uint8).reshape(1024, 1024, 4)
         return check(lib().frt_scene_add_texture(self._h, 1, t.ctypes.data))
 
+    # builder.rs:191-292 / :294-300 / :302-314 — `model` is a frt.loader.Model
+    def add_gltf_materials(self, model):
+        ids = np.zeros(max(model.counts()["materials"], 1), np.uint32)
+        n = check(lib().frt_scene_add_gltf_materials(self._h, model._h, ids.ctypes.data))
+        return ids[:n].copy()
+
+    def add_gltf_meshes(self, model):
+        ids = np.zeros(max(model.counts()["geometries"], 1), np.uint32)
+        n = check(lib().frt_scene_add_gltf_meshes(self._h, model._h, ids.ctypes.data))
+        return ids[:n].copy()
+
+    def add_gltf_instances(self, model, mesh_ids, mat_ids, transform_colmajor):
+        me = np.ascontiguousarray(mesh_ids, np.uint32); ma = np.ascontiguousarray(mat_ids, np.uint32)
+        m = np.ascontiguousarray(transform_colmajor, np.float32).reshape(16)
+        return check(lib().frt_scene_add_gltf_instances(self._h, model._h, me.ctypes.data, me.size, ma.ctypes.data, ma.size, m.ctypes.data))
+
     # builder.rs:431
     def build(self):
         check(lib().frt_scene_build(self._h))

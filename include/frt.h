@@ -107,6 +107,31 @@ int frt_scene_build(frt_scene* s);
 frt_scene* frt_scene_create_cornell_box(void);
 frt_scene* frt_scene_create_restir_scene(void);
 
+/* ---- model import: src/scene/loader.rs:9-181 load_gltf (+ a Wavefront OBJ subset, an extension) -------------------------
+ * frt_model = the (geometries, materials, images, material_indices) tuple load_gltf returns: one geometry per mesh primitive,
+ * images decoded and Lanczos3-resized to 1024 x 1024 RGBA8 (JPEG and non-RGB(A)8 PNGs become the white fallback texture of
+ * loader.rs:35-44; see frt_model_warning), materials built as loader.rs:58-99 does (metallic is always 1: material.rs:54-58).
+ * Material texture slots hold IMAGE indices until frt_scene_add_gltf_materials remaps them to texture-array layers. */
+typedef struct frt_model frt_model;
+frt_model* frt_model_load(const char* path);                 /* .gltf / .glb / .vrm, or .obj; NULL + frt_last_error on failure */
+void frt_model_destroy(frt_model* m);
+int frt_model_counts(const frt_model* m, uint32_t counts[4]);      /* geometries, materials, images, warnings */
+int frt_model_geometry_counts(const frt_model* m, uint32_t geo, uint32_t* nverts, uint32_t* nidx, uint32_t* material_index);
+int frt_model_geometry_get(const frt_model* m, uint32_t geo, float* pos4, frt_vertex_attr* attrs, uint32_t* idx);   /* any pointer may be NULL */
+int frt_model_material_get(const frt_model* m, uint32_t i, frt_material* out);
+int frt_model_material_set(frt_model* m, uint32_t i, const frt_material* in);   /* scenes.rs:392-410 rewrites loaded materials before adding them */
+int frt_model_image_get(const frt_model* m, uint32_t i, uint8_t* rgba8_1024x1024);
+const char* frt_model_warning(const frt_model* m, uint32_t i);    /* what the reference prints to stdout; NULL past the end */
+/* src/scene/builder.rs:191-292, :294-300, :302-314. ids arrays are caller-owned ([materials] / [geometries]); return = count written */
+int frt_scene_add_gltf_materials(frt_scene* s, const frt_model* m, uint32_t* mat_ids);
+int frt_scene_add_gltf_meshes(frt_scene* s, const frt_model* m, uint32_t* mesh_ids);
+int frt_scene_add_gltf_instances(frt_scene* s, const frt_model* m, const uint32_t* mesh_ids, uint32_t n_mesh, const uint32_t* mat_ids, uint32_t n_mat,
+                                 const float transform_colmajor[16]);
+/* src/scene/scenes.rs:246-322 create_gltf_scene (floor plane, 15-intensity quad light, the model; built). Differs from the
+ * reference in one error case: there a model that fails to load is logged and an EMPTY scene is built; here the call returns
+ * NULL with the loader's message in frt_last_error (scenes without triangles cannot be built). */
+frt_scene* frt_scene_create_gltf_scene(const char* path, const float model_transform_colmajor[16], const float light_transform_colmajor[16]);
+
 /* Introspection (tests): counts[8] = tris, instances, materials, lights, meshes, attributes, indices, bvh2 nodes */
 int frt_scene_counts(const frt_scene* s, uint32_t counts[8]);
 /* which: 0 tris (9 f32: v0,e1,e2), 1 tri_instance (u32), 2 materials, 3 lights, 4 attributes, 5 indices, 6 mesh infos (16 B),
