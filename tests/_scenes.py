@@ -152,3 +152,41 @@ def moving_camera_uniforms(frt, aspect, num_lights, frames, step=(0.02, 0.01, -0
         out.append(cu)
         prev_vp = vp
     return out
+
+
+def gltf_scene(frt, orc, path, model_transform, light_transform):
+    """scenes.rs:246-322 through the product (frt.scenes.create_gltf_scene) and, for the oracle, the same scene re-issued call by
+    call from the loaded model: the meshes from frt.loader, materials / lights / instances as the product built them, and the
+    texture layers in the order tests/_gltf.py::assign_layers (an independent restatement of builder.rs:191-292) derives."""
+    import _gltf
+    from _oracle import OrcScene
+    fs = frt.scenes.create_gltf_scene(path, model_transform, light_transform)
+    model = frt.loader.load_gltf(path)
+    oh = orc.L.orc_scene_create()
+
+    def add_mesh(g):
+        pos = np.ascontiguousarray(g.positions, np.float32); att = np.ascontiguousarray(g.attributes, np.float32); idx = np.ascontiguousarray(g.indices, np.uint32)
+        return orc.L.orc_scene_add_mesh(oh, pos.ctypes.data, pos.shape[0], att.ctypes.data, idx.ctypes.data, idx.size)
+    add_mesh(frt.geometry.create_plane()); add_mesh(frt.geometry.create_plane())
+    n = model.counts()
+    for i in range(n["geometries"]):
+        add_mesh(model.geometry(i)[0])
+
+    def tex(m):
+        f = lambda v: None if v == 0xFFFF else v
+        return (f(m.tex_info_0 & 0xFFFF), f(m.tex_info_0 >> 16), f(m.tex_info_1 & 0xFFFF), f(m.tex_info_1 >> 16), f(m.tex_info_2 & 0xFFFF))
+    _, corder, dorder = _gltf.assign_layers([tex(model.material(i)) for i in range(n["materials"])], 3, 3)
+    for kind, order in ((0, corder), (1, dorder)):
+        for img in order:
+            t = np.ascontiguousarray(model.image(img))
+            orc.L.orc_scene_add_texture(oh, kind, t.ctypes.data)
+    for row in fs.get("materials"):
+        r = np.ascontiguousarray(row); orc.L.orc_scene_add_material(oh, r.ctypes.data)
+    for row in fs.get("lights"):
+        r = np.ascontiguousarray(row); orc.L.orc_scene_add_light(oh, r.ctypes.data)
+    for row in fs.get("instances"):
+        m = np.ascontiguousarray(row[5:21]); orc.L.orc_scene_add_instance(oh, int(row[0]), int(row[1]), m.ctypes.data)
+    orc.L.orc_scene_build(oh)
+    osc = OrcScene(orc, oh)
+    osc.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    return fs, osc

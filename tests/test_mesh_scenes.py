@@ -47,3 +47,48 @@ def test_mesh_scenes_on_gpu(frt, orc, which):
     assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
     acc = r.read_accum()
     assert acc[..., :3].mean() > 0.01 and not np.isnan(acc).any()
+
+
+def _textured_gltf(frt, orc, tmp_path):
+    """A glTF model that uses all five texture kinds (base colour, normal, occlusion, emissive, metallic-roughness), placed by
+    create_gltf_scene with the transforms of scenes.rs:331-338 (model scaled, light at y = 5 turned to face down)."""
+    from test_loader import _sphere_model
+    path, _ = _sphere_model(tmp_path, frt)
+    L = np.eye(4, dtype=np.float32); L[1, 1] = -1.0; L[2, 2] = -1.0; L[3, 1] = 5.0
+    M = np.eye(4, dtype=np.float32) * np.float32(2.0); M[3, 3] = 1.0
+    return _scenes.gltf_scene(frt, orc, path, M.reshape(16), L.reshape(16))
+
+
+def test_textured_gltf_scene_host_parity(frt, orc, hostcheck, tmp_path):
+    fs, os_ = _textured_gltf(frt, orc, tmp_path)
+    for k in ("tris", "tri_instance", "materials", "lights", "instances"):
+        assert fs.get(k).tobytes() == os_.get(k).tobytes(), k
+    W, H = 80, 60
+    ro = os_.renderer(W, H, 8, True, 8); rh = hostcheck.renderer(fs, W, H, 8, 8)
+    for f in range(3):
+        cam = frt.CameraController().build_uniform(W / H, f, 1)
+        ro.render(cam); rh.render(cam)
+        compare_all(rh.read, ro.read, f, "textured glTF")
+    alb = ro.read(2, 0).reshape(H, W, 4)
+    assert len(np.unique(alb.reshape(-1, 4), axis=0)) > 200          # the base-colour texture reaches the G-buffer
+    nrm = ro.read(1, 0).view(np.float32).reshape(H, W, 4)
+    hit = ro.read(0, 0).view(np.float32).reshape(H, W, 4)[..., 3] >= 0
+    assert hit.mean() > 0.5 and len(np.unique(nrm[hit][:, :2], axis=0)) > 500    # normal map perturbs the shading normal
+
+
+@pytest.mark.gpu
+def test_textured_gltf_scene_on_gpu(frt, orc, tmp_path):
+    if frt.lib().frt_device_count() < 1:
+        pytest.fail("no HIP device")
+    fs, os_ = _textured_gltf(frt, orc, tmp_path)
+    W, H, depth = 192, 108, 8
+    r = frt.Renderer(fs, W, H, max_depth=depth)
+    ro = os_.renderer(W, H, depth, True, 16)
+    for f in range(4):
+        cam = frt.CameraController().build_uniform(W / H, f, 1)
+        r.render(cam); ro.render(cam)
+        compare_all(r.read_buffer, ro.read, f, "textured glTF")
+    st, so = r.stats(), ro.stats()["total"]
+    assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
+    acc = r.read_accum()
+    assert acc[..., :3].mean() > 0.01 and not np.isnan(acc).any()
