@@ -342,7 +342,9 @@ __global__ void __launch_bounds__(kBlock) post_kernel(FrameView fv) {
 
 static dim3 grid_for(const FrameView& fv) { return dim3((fv.W + 15u) / 16u, (fv.y1 - fv.y0 + 15u) / 16u, 1u); }
 
-hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const StageLaunch& L) {
+hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const StageLaunch& L,
+                        hipStream_t tail, hipEvent_t ev, bool* tail_used) {
+    if (tail_used) *tail_used = false;
     if (fv.y1 <= fv.y0 || fv.W == 0u) return hipSuccess;
     dim3 grid = grid_for(fv), block(kBlock);
     if (stage == 0) hipLaunchKernelGGL(gbuffer_kernel, grid, block, 0, stream, sc, fv);
@@ -353,18 +355,24 @@ hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hip
         if (stage == 1) hipLaunchKernelGGL(compact_kernel<1>, cgrid, cblock, 0, stream, sc, fv);
         else hipLaunchKernelGGL(compact_kernel<2>, cgrid, cblock, 0, stream, sc, fv);
     } else {
-        // pixel kernel up to the first cut, then one continuation launch per further segment, ping-ponging the two queues
-        const ContQueue* q = L.queues;   // [0], [1]
+        // pixel kernel up to the first cut, then one continuation launch per further segment
+        auto queue = [&](uint32_t k) { ContQueue q; q.words = L.qwords[k & 1u]; q.count = L.counts + k; q.capacity = L.capacity; return q; };
         uint32_t first = L.ncuts ? L.cuts[0] : fv.max_depth;
-        if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, block, 0, stream, sc, fv, q[0], first);
-        else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv, q[0], first);
-        dim3 qgrid((q[0].capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
-        int in = 0;
+        if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, block, 0, stream, sc, fv, queue(0), first);
+        else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv, queue(0), first);
+        dim3 qgrid((L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
+        hipStream_t cs = stream;
+        if (tail && ev && L.ncuts && L.cuts[0] < fv.max_depth) {
+            hipError_t e = hipEventRecord(ev, stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(tail, ev, 0);
+            if (e != hipSuccess) return e;
+            cs = tail;
+            if (tail_used) *tail_used = true;
+        }
         for (uint32_t k = 0; k < L.ncuts && L.cuts[k] < fv.max_depth; ++k) {
             uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
-            if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, qgrid, block, 0, stream, sc, fv, q[in], q[in ^ 1], d0, d1);
-            else hipLaunchKernelGGL(continue_kernel<2>, qgrid, block, 0, stream, sc, fv, q[in], q[in ^ 1], d0, d1);
-            in ^= 1;
+            if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, qgrid, block, 0, cs, sc, fv, queue(k), queue(k + 1), d0, d1);
+            else hipLaunchKernelGGL(continue_kernel<2>, qgrid, block, 0, cs, sc, fv, queue(k), queue(k + 1), d0, d1);
         }
     }
     return hipGetLastError();

@@ -3,9 +3,14 @@
 #include "frt_mono.hpp"
 
 namespace frt {
-// How to launch the traced stages: default = pixel kernel cut at cuts[0] + continuation launches over the queues (two ContQueue
-// per stage, zero counts before the stage runs); compaction = the opt-in workgroup-compacting kernels.
-struct StageLaunch { bool compaction; uint32_t ncuts; uint32_t cuts[4]; ContQueue queues[2]; };
-// stage: 0 G-buffer, 1 temporal, 2 spatial + shade, 3 post. Rows [fv.y0, fv.y1). Asynchronous on `stream`.
-hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const StageLaunch& L);
+// How to launch the traced stages: default = pixel kernel cut at cuts[0] + one continuation launch per further segment. The two
+// word buffers are used alternately; every segment has its OWN counter (counts[0 .. ncuts], zero before the stage runs), so a
+// buffer that is written again two launches later starts from slot 0. compaction = the opt-in workgroup-compacting kernels.
+static constexpr int kMaxCuts = 4;
+struct StageLaunch { bool compaction; uint32_t ncuts; uint32_t cuts[kMaxCuts]; uint32_t* qwords[2]; uint32_t* counts; uint32_t capacity; };
+// stage: 0 G-buffer, 1 temporal, 2 spatial + shade, 3 post. Rows [fv.y0, fv.y1). Asynchronous on `stream`. With `tail` set, the
+// continuation launches of a traced stage go to that stream instead, ordered after the pixel kernel through `ev`; *tail_used
+// tells whether anything was put there.
+hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const StageLaunch& L,
+                        hipStream_t tail = nullptr, hipEvent_t ev = nullptr, bool* tail_used = nullptr);
 }

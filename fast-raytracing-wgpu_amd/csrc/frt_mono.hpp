@@ -55,8 +55,9 @@ FRT_HD f3 nee(PathCtx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_co
     return splat3(0.0f);
 }
 
-// State of a path at the top of the bounce loop (restir.wgsl:590): everything an iteration reads that earlier code wrote.
-// A path can be cut here, parked in HBM (frt_kernels.hip: continuation queue) and resumed by another lane.
+// State of a path between two bounce iterations (restir.wgsl:590), after the Russian-roulette test that opens the next iteration:
+// everything the rest of that iteration reads that earlier code wrote. A path can be cut here, parked in HBM (frt_kernels.hip:
+// continuation queue) and resumed by another lane.
 struct LoopState {
     f3 pos, ffnormal, throughput, accumulated, next_dir, v1_pos;
     float last_bsdf_pdf;
@@ -137,7 +138,7 @@ FRT_HD void path_head(PathCtx& c, uint32_t pix, uint32_t seed, LoopState& s) {
     s.next_dir = sc0.wi;
     s.pos = hit.pos; s.ffnormal = hit.ffnormal;
     s.previous_was_diffuse = previous_was_diffuse; s.is_glass = is_glass;
-    s.alive = true;
+    s.alive = 1u < fv.max_depth;      // iteration 1 exists (no roulette before depth 3)
 }
 
 // Bounce loop, iterations depth_begin .. depth_end-1 of `for (depth = 1; depth < MAX_DEPTH; depth++)` (restir.wgsl:590-733).
@@ -155,12 +156,6 @@ FRT_HD void path_loop(PathCtx& c, LoopState& s, uint32_t depth_begin, uint32_t d
     bool alive = true;
     for (uint32_t depth = depth_begin; depth < depth_end; depth++) {
         alive = false;
-        if (depth >= 3u) {
-            float p = fmaxn(throughput.x, fmaxn(throughput.y, throughput.z));
-            float survival_prob = clampf(p, 0.05f, 0.95f);
-            if (c.rand() > survival_prob) break;
-            throughput = throughput / survival_prob;
-        }
         f3 offset_dir = hit.ffnormal * signf(dot(hit.ffnormal, next_dir));
         f3 origin = hit.pos + offset_dir * 0.001f;
         HitRec h;
@@ -224,11 +219,22 @@ FRT_HD void path_loop(PathCtx& c, LoopState& s, uint32_t depth_begin, uint32_t d
         last_bsdf_pdf = sb.pdf;
         throughput = throughput * sb.weight;
         next_dir = sb.wi;
+        // Russian roulette of the NEXT iteration (restir.wgsl:593-598, the first statements of the loop body), taken here so that a
+        // path the roulette kills is never parked at a cut. Nothing draws from the stream between sample_bsdf and this test, and the
+        // draw is skipped exactly when the reference's loop condition would end the loop, so the sequence of rand() calls is the same.
+        const uint32_t next = depth + 1u;
+        if (next >= fv.max_depth) break;
+        if (next >= 3u) {
+            float p = fmaxn(throughput.x, fmaxn(throughput.y, throughput.z));
+            float survival_prob = clampf(p, 0.05f, 0.95f);
+            if (c.rand() > survival_prob) break;
+            throughput = throughput / survival_prob;
+        }
         alive = true;
     }
     s.pos = hit.pos; s.ffnormal = hit.ffnormal; s.accumulated = accumulated; s.throughput = throughput; s.next_dir = next_dir;
     s.last_bsdf_pdf = last_bsdf_pdf; s.previous_was_diffuse = previous_was_diffuse;
-    s.alive = alive && depth_end < fv.max_depth;
+    s.alive = alive;      // still running: the roulette for iteration depth_end has been passed
 }
 
 // ---- continuation records: a LoopState parked in HBM between two launches -------------------------------------------------

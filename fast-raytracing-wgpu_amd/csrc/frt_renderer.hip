@@ -39,8 +39,8 @@ struct frt_renderer {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side = nullptr;            // FRT_FLAG_OVERLAP_POST: the post stage runs here
-    hipEvent_t ev_spatial = nullptr, ev_post = nullptr;
-    bool post_in_flight = false;
+    hipEvent_t ev_spatial = nullptr, ev_post = nullptr, ev_smain = nullptr, ev_scont = nullptr;
+    bool post_in_flight = false, scont_in_flight = false;
     uint32_t W = 0, H = 0, max_depth = 8, rb = 0, re = 0, flags = 0;
     uint32_t frame_count = 0;
     SceneView sv{};
@@ -51,8 +51,8 @@ struct frt_renderer {
     size_t off[B_COUNT] = {};
     unsigned long long* d_counters = nullptr;
     uint32_t* d_qwords = nullptr;          // continuation queues: [stage 1|2][A|B] x kContWordsSpatial x npix words
-    uint32_t* d_qcount = nullptr;          // their 4 counters
-    uint32_t ncuts = 1, cuts[4] = {4, 0, 0, 0};   // measured best on the Cornell Box (tools/ab.py sweep: 0 / 3 / 4 / 5 / 2,4 / 4,6)
+    uint32_t* d_qcount = nullptr;          // per stage, one counter per path segment (kMaxCuts + 1)
+    uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box (sweep over 0 / 2 / 3 / 4 / 5 and multi-cut sets)
     frt_stats stats{};
     struct Timed { hipEvent_t a, b; int stage; };
     std::vector<Timed> pending;
@@ -306,6 +306,8 @@ void frt_renderer_destroy(frt_renderer* r) {
     if (r->side) { (void)hipStreamSynchronize(r->side); (void)hipStreamDestroy(r->side); }
     if (r->ev_spatial) (void)hipEventDestroy(r->ev_spatial);
     if (r->ev_post) (void)hipEventDestroy(r->ev_post);
+    if (r->ev_smain) (void)hipEventDestroy(r->ev_smain);
+    if (r->ev_scont) (void)hipEventDestroy(r->ev_scont);
     for (auto& t : r->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (void* p : r->scene_allocs) (void)hipFree(p);
     if (r->own_arena && r->arena) (void)hipFree(r->arena);
@@ -328,6 +330,8 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&r->ev_spatial, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&r->ev_post, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_smain, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_scont, hipEventDisableTiming));
     }
     r->arena_bytes = arena_layout(r->W, r->H, r->off);
     if (o && o->device_arena) {
@@ -341,14 +345,14 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     {   // continuation queues (worst case: every pixel parks) and the bounce depths at which paths are cut
         size_t npix = (size_t)r->W * r->H;
         HIP_TRY(hipMalloc((void**)&r->d_qwords, 4 * (size_t)kContWordsSpatial * npix * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&r->d_qcount, 4 * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&r->d_qcount, 2 * (kMaxCuts + 1) * sizeof(uint32_t)));
         // Parking pays when the launch saturates the chip (>= ~0.6 M pixels: +6 % at 1080p, +5 % at half a frame); a thin strip
         // is bound by the latency of its longest path and the extra launch only adds to it (tools/strip_time.py: 0.79 vs 0.70 ms
         // for 1/8 of a 1080p frame), so thin strips run uncut.
         if ((size_t)r->W * (r->re - r->rb) < 600000u) r->ncuts = 0;
         if (const char* e = getenv("FRT_CUTS")) {   // experiment knob: comma-separated ascending depths, "0" = never cut
             r->ncuts = 0;
-            for (const char* p = e; *p && r->ncuts < 4;) {
+            for (const char* p = e; *p && r->ncuts < (uint32_t)kMaxCuts;) {
                 uint32_t v = (uint32_t)strtoul(p, (char**)&p, 10);
                 if (v >= 1) r->cuts[r->ncuts++] = v;
                 if (*p == ',') ++p;
@@ -387,21 +391,29 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
     fill_frame_view(r, cam, fv);
     uint32_t rows[8];
     phase_rows(r, rows);
-    if (phases & (FRT_PHASE_TEMPORAL | FRT_PHASE_SPATIAL)) HIP_TRY(hipMemsetAsync(r->d_qcount, 0, 4 * sizeof(uint32_t), r->stream));
     for (int stage = 0; stage < 4; ++stage) {
         if (!(phases & (1 << stage))) continue;
         fv.y0 = rows[2 * stage]; fv.y1 = rows[2 * stage + 1];
         fv.ray_counters = r->d_counters + 2 * stage;
         hipStream_t q = r->stream;
-        if (r->side && stage == 3) {   // post(f) on the side stream, after spatial(f)
+        // Side-stream schedule (FRT_FLAG_OVERLAP_POST): the tail of frame f — spatial continuation, then post — runs on the side
+        // stream while the main stream already runs G-buffer(f+1) (independent of frame f) and, once the continuation is done,
+        // temporal(f+1) (reads the spatial reservoirs the continuation finishes; overlaps post(f)).
+        if (r->side && stage == 3) {   // post(f) after spatial(f): its pixel kernel (main) and its continuation (side, in order)
             HIP_TRY(hipEventRecord(r->ev_spatial, r->stream));
             HIP_TRY(hipStreamWaitEvent(r->side, r->ev_spatial, 0));
             q = r->side;
+        }
+        if (r->side && (stage == 1 || stage == 2) && r->scont_in_flight) {
+            HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_scont, 0));
+            r->scont_in_flight = false;
         }
         if (r->side && stage == 2 && r->post_in_flight) {   // spatial(f+1) overwrites the radiance post(f) reads
             HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0));
             r->post_in_flight = false;
         }
+        if (stage == 1 || stage == 2)   // this stage's segment counters (after the waits: the previous frame's tail used them)
+            HIP_TRY(hipMemsetAsync(r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1), 0, (kMaxCuts + 1) * sizeof(uint32_t), r->stream));
         frt_renderer::Timed t{};
         bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
         if (timed) {
@@ -411,17 +423,17 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
         StageLaunch L{};
         L.compaction = (r->flags & FRT_FLAG_COMPACTION) != 0;
         L.ncuts = r->ncuts;
-        for (int k = 0; k < 4; ++k) L.cuts[k] = r->cuts[k];
+        for (int k = 0; k < kMaxCuts; ++k) L.cuts[k] = r->cuts[k];
         if (stage == 1 || stage == 2) {
             size_t npix = (size_t)r->W * r->H, qsz = (size_t)kContWordsSpatial * npix;
-            for (int k = 0; k < 2; ++k) {
-                L.queues[k].words = r->d_qwords + (size_t)(2 * (stage - 1) + k) * qsz;
-                L.queues[k].count = r->d_qcount + 2 * (stage - 1) + k;
-                L.queues[k].capacity = (uint32_t)npix;
-            }
+            for (int k = 0; k < 2; ++k) L.qwords[k] = r->d_qwords + (size_t)(2 * (stage - 1) + k) * qsz;
+            L.counts = r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1);
+            L.capacity = (uint32_t)npix;
         }
-        HIP_TRY(launch_stage(stage, r->sv, fv, q, L));
-        if (timed) { HIP_TRY(hipEventRecord(t.b, q)); r->pending.push_back(t); }
+        bool on_side = false;
+        HIP_TRY(launch_stage(stage, r->sv, fv, q, L, (r->side && stage == 2) ? r->side : nullptr, r->ev_smain, &on_side));
+        if (on_side) { HIP_TRY(hipEventRecord(r->ev_scont, r->side)); r->scont_in_flight = true; }
+        if (timed) { HIP_TRY(hipEventRecord(t.b, on_side ? r->side : q)); r->pending.push_back(t); }
         if (r->side && stage == 3) { HIP_TRY(hipEventRecord(r->ev_post, r->side)); r->post_in_flight = true; }
         if (r->side && stage == 1 && r->post_in_flight) {
             // temporal(f+1) may overlap post(f); whatever the caller enqueues next on the main stream (the halo exchange of the

@@ -218,3 +218,22 @@ def test_post_overlap_flag_gives_identical_frames(gpu, orc):
     want = ro.read(7, last)
     for s, p in zip(strips, plans):
         assert s.read_buffer(7, last)[p.row_begin:p.row_end].tobytes() == want[p.row_begin:p.row_end].tobytes()
+
+
+@pytest.mark.parametrize("cuts", ["0", "3", "2,3,5,6", "1,2,3,4", "5,7"])
+def test_every_cut_configuration_is_bit_identical(gpu, orc, monkeypatch, cuts):
+    """The continuation-queue protocol (pixel kernel -> park after the roulette -> continue kernels, one counter per segment) must
+    not depend on where or how often paths are cut. FRT_CUTS is the experiment knob frt_renderer_create reads."""
+    frt = gpu
+    monkeypatch.setenv("FRT_CUTS", cuts)
+    W, H, depth = 160, 96, 8
+    fs = frt.scenes.create_cornell_box()
+    os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    r = frt.Renderer(fs, W, H, max_depth=depth)
+    ro = os_.renderer(W, H, depth, True, 16)
+    for f in range(4):
+        cam = frt.CameraController().build_uniform(W / H, f, 2)
+        r.render(cam); ro.render(cam)
+        compare_all(r.read_buffer, ro.read, f, f"cuts {cuts}")
+    st, so = r.stats(), ro.stats()["total"]
+    assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])

@@ -6,8 +6,10 @@ import frt
 W, H = 1920, 1080
 scene = frt.scenes.create_cornell_box()
 cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(40)]
-for cuts, extra in (("default", 0), ("default+overlap_post", frt.FLAG_OVERLAP_POST)):
-    for world in (2, 4, 8):
+for cuts, extra in (("0", frt.FLAG_OVERLAP_POST), ("3", frt.FLAG_OVERLAP_POST), ("default", frt.FLAG_OVERLAP_POST)):
+    if cuts == "default": os.environ.pop("FRT_CUTS", None)      # the renderer's own rule (uncut below 0.6 M pixels)
+    else: os.environ["FRT_CUTS"] = cuts                         # read by frt_renderer_create
+    for world in (1, 2, 4, 8):
         worst = 0
         for rank in range(world):
             rb, re = H * rank // world, H * (rank + 1) // world
