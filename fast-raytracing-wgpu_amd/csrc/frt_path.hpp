@@ -260,6 +260,7 @@ FRT_HD void temporal_finalize(PathCtx& c, const PathState& st) {
         uint32_t qx = (uint32_t)pf.x, qy = (uint32_t)pf.y;
         bool inb = qx < fv.W && qy < fv.H;          // prev_uv == 1.0: out-of-range texel reads give zeros
         uint32_t prev_idx = inb ? qy * fv.W + qx : 0u;
+        if (inb && (qy < fv.prev_y0 || qy >= fv.prev_y1)) note_halo_overflow(fv);
         float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float4 prev_pos = inb ? fv.gpos_prev[prev_idx] : zero4;
         float4 prev_nrm = inb ? fv.gnormal_prev[prev_idx] : zero4;

@@ -41,7 +41,7 @@ struct frt_renderer {
     hipStream_t side = nullptr;            // FRT_FLAG_OVERLAP_POST: the post stage runs here
     hipEvent_t ev_spatial = nullptr, ev_post = nullptr, ev_smain = nullptr, ev_scont = nullptr;
     bool post_in_flight = false, scont_in_flight = false;
-    uint32_t W = 0, H = 0, max_depth = 8, rb = 0, re = 0, flags = 0;
+    uint32_t W = 0, H = 0, max_depth = 8, rb = 0, re = 0, flags = 0, motion_halo = 0;
     uint32_t frame_count = 0;
     SceneView sv{};
     std::vector<void*> scene_allocs;
@@ -112,7 +112,8 @@ static void phase_rows(const frt_renderer* r, uint32_t out[8]) {
     bool whole = (r->rb == 0 && r->re == r->H);
     auto lo = [&](uint32_t h) { return whole ? 0u : (r->rb > h ? r->rb - h : 0u); };
     auto hi = [&](uint32_t h) { return whole ? r->H : std::min(r->H, r->re + h); };
-    out[0] = lo(kHaloGbuffer); out[1] = hi(kHaloGbuffer);
+    const uint32_t hg = std::max(kHaloGbuffer, r->motion_halo);   // temporal(f+1) reprojects into the previous G-buffer within the motion halo
+    out[0] = lo(hg); out[1] = hi(hg);
     out[2] = r->rb; out[3] = r->re;
     out[4] = lo(kHaloSpatial); out[5] = hi(kHaloSpatial);
     out[6] = r->rb; out[7] = r->re;
@@ -132,6 +133,10 @@ static void fill_frame_view(const frt_renderer* r, const frt_camera_uniform* cam
     fv.ray_counters = r->d_counters;
     fv.W = r->W; fv.H = r->H; fv.frame_count = r->frame_count; fv.max_depth = r->max_depth;
     fv.own_y0 = r->rb; fv.own_y1 = r->re;
+    bool whole = (r->rb == 0 && r->re == r->H);
+    fv.prev_y0 = whole ? 0u : (r->rb > r->motion_halo ? r->rb - r->motion_halo : 0u);
+    fv.prev_y1 = whole ? r->H : std::min(r->H, r->re + r->motion_halo);
+    fv.overflow = whole ? nullptr : r->d_counters + 8;
     memcpy(&fv.cam, cam, sizeof(CameraView));
 }
 
@@ -341,7 +346,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     } else {
         HIP_TRY(hipMalloc((void**)&r->arena, r->arena_bytes)); r->own_arena = true;
     }
-    HIP_TRY(hipMalloc((void**)&r->d_counters, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&r->d_counters, 9 * sizeof(unsigned long long)));   // 4 stages x {closest, any} + halo overflow
     {   // continuation queues (worst case: every pixel parks) and the bounce depths at which paths are cut
         size_t npix = (size_t)r->W * r->H;
         HIP_TRY(hipMalloc((void**)&r->d_qwords, 4 * (size_t)kContWordsSpatial * npix * sizeof(uint32_t)));
@@ -360,7 +365,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         }
     }
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));   // wgpu zero-initialises textures and buffers
-    HIP_TRY(hipMemsetAsync(r->d_counters, 0, 8 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_counters, 0, 9 * sizeof(unsigned long long), r->stream));
     int rc = upload_scene(r, s->b);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -379,6 +384,7 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
     if (o && !(o->row_begin == 0 && o->row_end == 0)) {
         if (o->row_begin >= o->row_end || o->row_end > height) { fail(FRT_ERR_INVALID_ARG, "renderer_create: bad row range"); delete r; return nullptr; }
         r->rb = o->row_begin; r->re = o->row_end;
+        r->motion_halo = o->motion_halo_rows;
     }
     if (renderer_init(r, s, o) != FRT_OK) { std::string keep = g_err; frt_renderer_destroy(r); g_err = keep; return nullptr; }
     return r;
@@ -474,7 +480,7 @@ int frt_renderer_clear(frt_renderer* r) {
     int rc = resolve_timing(r);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));
-    HIP_TRY(hipMemsetAsync(r->d_counters, 0, 8 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_counters, 0, 9 * sizeof(unsigned long long), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->frame_count = 0;
     memset(&r->stats, 0, sizeof(r->stats));
@@ -544,8 +550,9 @@ int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
     { int rc_ = sync_all(r); if (rc_) return rc_; }
     int rc = resolve_timing(r);
     if (rc) return rc;
-    unsigned long long c[8] = {0};
+    unsigned long long c[9] = {0};
     HIP_TRY(hipMemcpy(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    r->stats.halo_overflow = c[8];
     r->stats.rays_closest = 0; r->stats.rays_any = 0;
     for (int st = 0; st < 4; ++st) {
         r->stats.rays_stage[st][0] = c[2 * st]; r->stats.rays_stage[st][1] = c[2 * st + 1];

@@ -28,8 +28,20 @@ struct FrameView {
     unsigned long long* ray_counters;   // [0] closest, [1] any
     uint32_t W, H, frame_count, max_depth, y0, y1;
     uint32_t own_y0, own_y1;         // rows whose rays are counted (a strip's redundant halo rows are not)
+    uint32_t prev_y0, prev_y1;       // rows whose previous-frame reservoirs / G-buffer are valid here (whole frame: 0, H)
+    unsigned long long* overflow;    // counts previous-frame reads outside them (may be null)
     CameraView cam;
 };
+
+// A strip read previous-frame state it does not hold (camera moved further than the strip's motion halo): counted, not fatal.
+FRT_HD void note_halo_overflow(const FrameView& fv) {
+    if (!fv.overflow) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(fv.overflow, 1ull);
+#else
+    ++*fv.overflow;
+#endif
+}
 
 static constexpr float kPI = 3.14159265359f;   // restir.wgsl:4
 static constexpr float kInvPI = 1.0f / kPI;    // x / PI is evaluated as x * (1 / PI) (contract)
@@ -450,6 +462,7 @@ FRT_HD void post_pixel_t(const FrameView& fv, uint32_t px, uint32_t py, const Ta
                 int x = p0x + (k & 1), y = p0y + (k >> 1);
                 c4[k] = splat3(0.0f);
                 if (x >= 0 && y >= 0 && x < W && y < H) {
+                    if ((uint32_t)y + 1u < fv.prev_y0 || (uint32_t)y > fv.prev_y1) note_halo_overflow(fv);   // history rows: prev rows +- 1
                     float4 hv = fv.history[(uint32_t)y * fv.W + (uint32_t)x];
                     c4[k] = resolve_tonemap(mk3(hv.x, hv.y, hv.z));
                 }

@@ -33,12 +33,12 @@ class CameraUniform(C.Structure):   # src/camera.rs:4-15
 class RenderOpts(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p),
                 ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("device_arena", C.c_void_p),
-                ("arena_bytes", C.c_uint64), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("arena_bytes", C.c_uint64), ("flags", C.c_uint32), ("motion_halo_rows", C.c_uint32)]
 
 
 class Stats(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("frames", C.c_uint64),
-                ("ms_stage", C.c_double * 4), ("launches", C.c_uint64 * 4), ("rays_stage", (C.c_uint64 * 2) * 4)]
+                ("ms_stage", C.c_double * 4), ("launches", C.c_uint64 * 4), ("rays_stage", (C.c_uint64 * 2) * 4), ("halo_overflow", C.c_uint64)]
 
 
 assert C.sizeof(VertexAttr) == 32 and C.sizeof(Material) == 64 and C.sizeof(Light) == 64 and C.sizeof(CameraUniform) == 288

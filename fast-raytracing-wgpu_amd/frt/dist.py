@@ -10,6 +10,13 @@ horizontal strips (contiguous in row-major, so strips gather in place); the scen
 So ONE exchange per frame, between the temporal and spatial stages: 12 rows of reservoirs (32 B/px) and 1 row of the
 previous frame's accumulation (16 B/px) with each vertical neighbour. Everything else is local.
 
+Moving camera (StripPlan(motion_halo=K), Renderer(motion_halo=K)): the temporal stage reprojects into the PREVIOUS frame's spatial
+reservoirs and G-buffer (restir.wgsl:846-900) and post fetches the previous accumulation bilinearly at the reprojected position
+(post.wgsl:187-266), both up to K rows outside the strip as long as the camera moves less than that per frame. The previous G-buffer
+is local (the G-buffer halo grows to K rows); a SECOND exchange, before the temporal stage, brings K rows of the previous spatial
+reservoirs and K + 1 rows of the previous accumulation from each neighbour ("pre" transfers; the accumulation row then leaves the
+mid-frame exchange). Reads beyond the halo are counted (stats()["halo_overflow"]); check_halo() raises on them.
+
 `exchange_halos` is transport-agnostic: it moves `rows(...)` tensors with torch.distributed point-to-point ops
 (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" on CPU for tests).
 """
@@ -25,30 +32,40 @@ class StripPlan:
 
     boundaries: optional list of world + 1 ascending row indices (0 ... H), e.g. from balanced_boundaries(); default = equal strips."""
 
-    def __init__(self, height, world, rank, boundaries=None):
+    def __init__(self, height, world, rank, boundaries=None, motion_halo=0):
         assert 0 <= rank < world
-        self.H, self.world, self.rank = height, world, rank
+        self.H, self.world, self.rank, self.motion_halo = height, world, rank, int(motion_halo)
         if boundaries is None:
             boundaries = [height * k // world for k in range(world + 1)]
         assert len(boundaries) == world + 1 and boundaries[0] == 0 and boundaries[-1] == height
         self.boundaries = list(boundaries)
         self.row_begin, self.row_end = boundaries[rank], boundaries[rank + 1]
-        if world > 1 and min(b - a for a, b in zip(boundaries, boundaries[1:])) < HALO_RESERVOIR:
-            raise ValueError(f"a strip is thinner than the {HALO_RESERVOIR}-row halo: {boundaries}")
+        need = max(HALO_RESERVOIR, self.motion_halo + HALO_HISTORY)
+        if world > 1 and min(b - a for a, b in zip(boundaries, boundaries[1:])) < need:
+            raise ValueError(f"a strip is thinner than the {need}-row halo: {boundaries}")
 
-    def transfers(self, frame):
-        """[(peer, buf, index, send_rows, recv_rows)] for the exchange of frame `frame` (before its spatial stage)."""
+    def _pairs(self, buf, index, rows):
+        """Both neighbours: send my `rows` boundary rows, receive theirs into the rows just outside my strip."""
         out = []
         rb, re = self.row_begin, self.row_end
-        hist = (frame - 1) % 2          # post.rs:209-224: history = the slot written by the previous frame
         if self.rank > 0:               # upper neighbour owns rows < rb
-            out.append((self.rank - 1, BUF_RESERVOIR, 0, (rb, rb + HALO_RESERVOIR), (rb - HALO_RESERVOIR, rb)))
-            if frame > 0:
-                out.append((self.rank - 1, BUF_ACCUM, hist, (rb, rb + HALO_HISTORY), (rb - HALO_HISTORY, rb)))
+            out.append((self.rank - 1, buf, index, (rb, rb + rows), (rb - rows, rb)))
         if self.rank < self.world - 1:  # lower neighbour owns rows >= re
-            out.append((self.rank + 1, BUF_RESERVOIR, 0, (re - HALO_RESERVOIR, re), (re, re + HALO_RESERVOIR)))
-            if frame > 0:
-                out.append((self.rank + 1, BUF_ACCUM, hist, (re - HALO_HISTORY, re), (re, re + HALO_HISTORY)))
+            out.append((self.rank + 1, buf, index, (re - rows, re), (re, re + rows)))
+        return out
+
+    def transfers(self, frame, when="mid"):
+        """[(peer, buf, index, send_rows, recv_rows)] for frame `frame`.
+        when="mid": between its temporal and spatial stages (always); when="pre": before its temporal stage (moving camera only)."""
+        hist = (frame - 1) % 2          # post.rs:209-224: history = the slot written by the previous frame
+        if when == "pre":
+            if self.motion_halo == 0 or frame == 0:
+                return []
+            return (self._pairs(BUF_RESERVOIR, 1, self.motion_halo)             # previous spatial reservoirs (reservoir_buffers[1])
+                    + self._pairs(BUF_ACCUM, hist, self.motion_halo + HALO_HISTORY))
+        out = self._pairs(BUF_RESERVOIR, 0, HALO_RESERVOIR)
+        if frame > 0 and self.motion_halo == 0:
+            out += self._pairs(BUF_ACCUM, hist, HALO_HISTORY)
         return out
 
 
@@ -81,10 +98,11 @@ class ArenaRows:
             v.copy_(t, non_blocking=True)
 
 
-def exchange_halos(access, plan, frame, group=None):
-    """One batched point-to-point exchange with both vertical neighbours (torch.distributed; nccl = RCCL, or gloo)."""
+def exchange_halos(access, plan, frame, group=None, when="mid"):
+    """One batched point-to-point exchange with both vertical neighbours (torch.distributed; nccl = RCCL, or gloo).
+    when="pre" (moving camera): call before the frame's G-buffer / temporal phases; when="mid": between temporal and spatial."""
     import torch.distributed as dist
-    tr = plan.transfers(frame)
+    tr = plan.transfers(frame, when)
     if not tr:
         return
     ops, recvs = [], []
@@ -99,11 +117,18 @@ def exchange_halos(access, plan, frame, group=None):
         access.store(buf, index, *rrows, rb)
 
 
-def exchange_halos_host(renderers, plans, frame):
+def check_halo(renderer):
+    """Raise if the strip read previous-frame state beyond its motion halo (the frame then differs from a 1-GPU frame)."""
+    n = renderer.stats()["halo_overflow"]
+    if n:
+        raise RuntimeError(f"{n} previous-frame reads fell outside the strip's motion halo: raise motion_halo (camera moves too fast for it)")
+
+
+def exchange_halos_host(renderers, plans, frame, when="mid"):
     """Same exchange between strip renderers living in ONE process (tests on a single GPU): rows go through host memory."""
     by_rank = {p.rank: r for r, p in zip(renderers, plans)}
     for r, p in zip(renderers, plans):
-        for peer, buf, index, srows, _ in p.transfers(frame):
+        for peer, buf, index, srows, _ in p.transfers(frame, when):
             data = r.read_rows(buf, index, *srows)
             by_rank[peer].write_rows(buf, index, *srows, data)     # the sender's rows land at the same image rows of the peer
 

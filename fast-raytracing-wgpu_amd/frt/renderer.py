@@ -5,8 +5,9 @@ from ._lib import (lib, check, FrtError, RenderOpts, Stats, CameraUniform, BUF_B
 
 
 class Renderer:
-    def __init__(self, scene, width, height, max_depth=8, device=0, stream=None, rows=None, arena=None, arena_bytes=0, flags=0):
-        """Renderer::new (renderer.rs:206). rows=(begin,end) restricts this renderer to an image strip."""
+    def __init__(self, scene, width, height, max_depth=8, device=0, stream=None, rows=None, arena=None, arena_bytes=0, flags=0, motion_halo=0):
+        """Renderer::new (renderer.rs:206). rows=(begin,end) restricts this renderer to an image strip; motion_halo = rows of
+        previous-frame state kept valid beyond the strip for a moving camera (frt.dist.StripPlan(motion_halo=...))."""
         o = RenderOpts()
         o.max_depth, o.device, o.flags = max_depth, device, flags
         if stream is not None:      # a caller-owned stream handle; 0 is the legacy default stream (torch's default current stream)
@@ -14,6 +15,7 @@ class Renderer:
             o.flags |= FLAG_USE_STREAM
         if rows is not None:
             o.row_begin, o.row_end = rows
+            o.motion_halo_rows = motion_halo
         if arena is not None:
             o.device_arena, o.arena_bytes = arena, arena_bytes
         self.width, self.height = width, height
@@ -97,4 +99,4 @@ class Renderer:
         check(lib().frt_renderer_stats(self._h, C.byref(s)))
         return {"rays_closest": s.rays_closest, "rays_any": s.rays_any, "frames": s.frames,
                 "ms_stage": list(s.ms_stage), "launches": list(s.launches),
-                "rays_stage": [[int(s.rays_stage[i][0]), int(s.rays_stage[i][1])] for i in range(4)]}
+                "rays_stage": [[int(s.rays_stage[i][0]), int(s.rays_stage[i][1])] for i in range(4)], "halo_overflow": int(s.halo_overflow)}

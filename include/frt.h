@@ -153,7 +153,10 @@ typedef struct frt_render_opts {
     void* device_arena;       /* optional caller-owned device memory for all per-pixel buffers (frt_renderer_arena_bytes) */
     uint64_t arena_bytes;
     uint32_t flags;           /* FRT_FLAG_* */
-    uint32_t reserved;
+    uint32_t motion_halo_rows;/* strips only: rows beyond the strip for which the caller keeps PREVIOUS-frame state valid (spatial reservoirs,
+                                 accumulation: frt/dist.py exchanges them before the temporal stage) so that temporal reprojection and the
+                                 history fetch of a MOVING camera may land there; the G-buffer halo grows to cover them. 0 = static camera.
+                                 Reads that fall outside are counted in frt_stats.halo_overflow (the frame then differs from a 1-GPU frame). */
 } frt_render_opts;
 #define FRT_FLAG_TIMING 1u          /* record per-stage HIP events every frame (frt_stats.ms_*) */
 #define FRT_FLAG_OVERLAP_POST 8u    /* run the post stage of frame f on a second stream, concurrently with G-buffer + temporal of frame f+1
@@ -183,6 +186,7 @@ typedef struct frt_stats {
     double ms_stage[4];       /* summed kernel time per stage (gbuffer, temporal, spatial, post); FRT_FLAG_TIMING only */
     uint64_t launches[4];     /* launches per stage */
     uint64_t rays_stage[4][2];/* per stage {closest, any}; post issues none */
+    uint64_t halo_overflow;   /* strips: previous-frame reads (reprojection, history) outside own rows +- motion_halo_rows; 0 for a whole frame */
 } frt_stats;
 
 uint64_t frt_renderer_arena_bytes(uint32_t width, uint32_t height);

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--port", type=int); ap.add_argument("--out"); ap.add_argument("--W", type=int, default=96)
     ap.add_argument("--H", type=int, default=64); ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--balanced", type=int, default=0)
+    ap.add_argument("--moving", type=int, default=0, help="motion halo rows K > 0: moving camera (tests/_scenes.py), two exchanges per frame")
     a = ap.parse_args()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world))
     import torch
@@ -46,16 +47,23 @@ def main():
     if a.balanced:
         from frt.dist import balanced_boundaries
         bounds = balanced_boundaries(frt, fs, W, H, a.world, bands=8)
-    plan = StripPlan(H, a.world, a.rank, bounds)
-    cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(N)]
+    K = a.moving
+    plan = StripPlan(H, a.world, a.rank, bounds, motion_halo=K)
+    if K:
+        import _scenes
+        cams = _scenes.moving_camera_uniforms(frt, W / H, 2, N)
+    else:
+        cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(N)]
     orc = Oracle(os.path.join(ROOT, "oracle", "_build", "liborc.so"))
     osc = orc.cornell(); osc.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
     rb, re = plan.row_begin, plan.row_end
     if a.mode == "oracle":
         r = osc.renderer(W, H, 8, True, 2)
         acc = OracleRows(r)
+        hg = max(12, K)
         for f in range(N):
-            r.render_phases(cams[f], 1, max(rb - 12, 0) if a.world > 1 else 0, min(re + 12, H) if a.world > 1 else H)
+            exchange_halos(acc, plan, f, when="pre")
+            r.render_phases(cams[f], 1, max(rb - hg, 0) if a.world > 1 else 0, min(re + hg, H) if a.world > 1 else H)
             r.render_phases(cams[f], 2, rb, re)
             exchange_halos(acc, plan, f)
             r.render_phases(cams[f], 4, max(rb - 2, 0), min(re + 2, H))
@@ -70,9 +78,10 @@ def main():
         arena = torch.empty(nbytes + 256, dtype=torch.uint8, device="cuda:0")
         off = (-arena.data_ptr()) % 256
         r = frt.Renderer(fs, W, H, rows=(rb, re), arena=arena.data_ptr() + off, arena_bytes=nbytes,
-                         stream=torch.cuda.current_stream().cuda_stream)
+                         stream=torch.cuda.current_stream().cuda_stream, motion_halo=K)
         acc = ArenaRows(r, arena, staging_device="cpu")
         for f in range(N):
+            exchange_halos(acc, plan, f, when="pre")
             r.render_phases(cams[f], frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
             exchange_halos(acc, plan, f)
             r.render_phases(cams[f], frt.PHASE_SPATIAL | frt.PHASE_POST)
@@ -80,6 +89,7 @@ def main():
         torch.cuda.synchronize()
         mine = torch.from_numpy(r.read_rows(7, (N - 1) % 2, rb, re).copy())
         st = r.stats(); rays = st["rays_closest"] + st["rays_any"]
+        assert st["halo_overflow"] == 0, st
     full = gather_strips(mine, plan).numpy()
     res = {"ok": True}
     if a.rank == 0:

@@ -117,7 +117,7 @@ void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     fv.gmotion = h->gmotion.data(); fv.res_temporal = h->res[0].data(); fv.res_spatial = h->res[1].data();
     fv.raw = h->raw.data(); fv.display = h->display.data(); fv.history = h->accum[prv].data(); fv.accum = h->accum[cur].data();
     fv.ray_counters = nullptr; fv.W = h->W; fv.H = h->H; fv.frame_count = h->frame_count; fv.max_depth = h->max_depth;
-    fv.y0 = 0; fv.y1 = h->H; fv.own_y0 = 0; fv.own_y1 = h->H;
+    fv.y0 = 0; fv.y1 = h->H; fv.own_y0 = 0; fv.own_y1 = h->H; fv.prev_y0 = 0; fv.prev_y1 = h->H; fv.overflow = nullptr;
     memcpy(&fv.cam, cam, sizeof(CameraView));
     int nt = h->nthreads;
     std::vector<unsigned long long> rc((size_t)nt * 2, 0ull);

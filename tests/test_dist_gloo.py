@@ -38,6 +38,14 @@ def test_strip_partition_matches_single_rank(frt, orc, tmp_path, world, H):
     assert res["ok"], res
 
 
+@pytest.mark.parametrize("world,H", [(2, 64), (3, 96)])
+def test_moving_camera_strips_match_single_rank(frt, orc, tmp_path, world, H):
+    """SURVEY §8f-2: with a moving camera the temporal stage reprojects into, and post fetches history from, rows of other strips;
+    a motion halo of K rows of previous-frame state (second exchange, before the temporal stage) restores bit equality."""
+    res = run_ranks("oracle", world, tmp_path, ("--H", str(H), "--W", "80", "--frames", "5", "--moving", "6"))
+    assert res["ok"], res
+
+
 def test_strip_plan_geometry(frt):
     from frt.dist import StripPlan
     plans = [StripPlan(1080, 8, k) for k in range(8)]
@@ -52,6 +60,16 @@ def test_strip_plan_geometry(frt):
     assert len(plans[0].transfers(0)) == 1 and len(plans[3].transfers(2)) == 4
     with pytest.raises(ValueError):
         StripPlan(64, 8, 0)
+    # moving camera: a second exchange before the temporal stage; the accumulation rows move there
+    mp = [StripPlan(1080, 8, k, motion_halo=16) for k in range(8)]
+    assert mp[2].transfers(0, "pre") == [] and len(mp[2].transfers(3, "pre")) == 4 and len(mp[2].transfers(3)) == 2
+    for when in ("pre", "mid"):
+        sends = {(q.rank, peer, buf, idx, s) for q in mp for peer, buf, idx, s, r in q.transfers(3, when)}
+        recvs = {(peer, q.rank, buf, idx, r) for q in mp for peer, buf, idx, s, r in q.transfers(3, when)}
+        assert sends == recvs
+    assert {(buf, idx, s[1] - s[0]) for _, buf, idx, s, _ in mp[2].transfers(3, "pre")} == {(4, 1, 16), (7, 0, 17)}
+    with pytest.raises(ValueError):
+        StripPlan(1080, 8, 0, motion_halo=200)
     # unequal (work-balanced) strips
     p = [StripPlan(100, 3, k, [0, 50, 70, 100]) for k in range(3)]
     assert (p[1].row_begin, p[1].row_end) == (50, 70)

@@ -175,6 +175,9 @@ def test_two_rank_strips_through_torch_distributed(gpu, tmp_path):
     res = run_ranks("gpu", 2, tmp_path, ("--H", "128", "--W", "160", "--frames", "4", "--balanced", "1"))
     assert res["ok"] and res["rays_all_ranks"] == res["oracle_rays"], res
     assert res["bounds"][1] != 64, res
+    # moving camera: motion halo of 6 rows, two exchanges per frame
+    res = run_ranks("gpu", 2, tmp_path, ("--H", "96", "--W", "160", "--frames", "5", "--moving", "6"))
+    assert res["ok"] and res["rays_all_ranks"] == res["oracle_rays"], res
 
 
 def test_moving_camera_on_gpu(gpu, orc):
@@ -237,3 +240,37 @@ def test_every_cut_configuration_is_bit_identical(gpu, orc, monkeypatch, cuts):
         compare_all(r.read_buffer, ro.read, f, f"cuts {cuts}")
     st, so = r.stats(), ro.stats()["total"]
     assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
+
+
+def test_moving_camera_strips_equal_whole_image(gpu):
+    """SURVEY §8f-2 on the GPU: three strip renderers with a motion halo + the two exchanges reproduce the single-renderer frames of a
+    moving camera bit for bit, with and without the side-stream schedule; without the halo the reads are detected (halo_overflow)."""
+    frt = gpu
+    import _scenes
+    from frt.dist import StripPlan, exchange_halos_host, check_halo
+    W, H, N, K = 192, 144, 6, 6
+    fs = frt.scenes.create_cornell_box()
+    cams = _scenes.moving_camera_uniforms(frt, W / H, 2, N)
+    whole = frt.Renderer(fs, W, H)
+    for c in cams: whole.render(c)
+    want = whole.read_accum(); wd = whole.read_display()
+    for flags, halo in ((0, K), (frt.FLAG_OVERLAP_POST, K), (0, 0)):
+        plans = [StripPlan(H, 3, k, motion_halo=halo) for k in range(3)]
+        strips = [frt.Renderer(fs, W, H, rows=(p.row_begin, p.row_end), motion_halo=halo, flags=flags) for p in plans]
+        for f, cam in enumerate(cams):
+            exchange_halos_host(strips, plans, f, when="pre")
+            for s in strips: s.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
+            exchange_halos_host(strips, plans, f)
+            for s in strips: s.render_phases(cam, frt.PHASE_SPATIAL | frt.PHASE_POST); s.end_frame()
+        same = all(np.array_equal(s.read_accum()[p.row_begin:p.row_end], want[p.row_begin:p.row_end]) and
+                   np.array_equal(s.read_display()[p.row_begin:p.row_end], wd[p.row_begin:p.row_end]) for s, p in zip(strips, plans))
+        if halo:
+            assert same, (flags, halo)
+            for s in strips: check_halo(s)
+            tot = sum(s.stats()["rays_closest"] + s.stats()["rays_any"] for s in strips)
+            assert tot == whole.stats()["rays_closest"] + whole.stats()["rays_any"]
+        else:
+            assert sum(s.stats()["halo_overflow"] for s in strips) > 0       # a static-camera plan under a moving camera is detected
+            with pytest.raises(RuntimeError):
+                for s in strips: check_halo(s)
+    assert whole.stats()["halo_overflow"] == 0
