@@ -20,6 +20,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs on this pool (task environment notes)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "fast-raytracing-wgpu_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
