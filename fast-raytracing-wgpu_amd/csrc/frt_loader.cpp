@@ -4,8 +4,10 @@
 //   gltf 1.4.1   gltf::import: JSON / GLB container, buffers (file, data: URI, BIN chunk), accessor reads incl. byteStride and the
 //                normalised-integer -> f32 conversion of tex-coords (`into_f32`), image decode to R8G8B8 / R8G8B8A8
 //   image 0.25.9 PNG decode; DynamicImage::resize_exact(.., Lanczos3) = vertical then horizontal pass in f32
-// JPEG-compressed images are NOT decoded in this build (no decoder in the image, none written yet): such an image becomes the
-// white 1024 x 1024 texture the reference substitutes for formats it does not handle (loader.rs:35-44), with a warning.
+//                baseline JPEG decode (the crate's decoder, zune-jpeg, differs from any other decoder by +-1 in places: the
+//                IDCT and the chroma upsampling are not bit-specified by the standard)
+// Progressive JPEGs, grey / 16-bit / interlaced PNGs are not decoded: such an image becomes the white 1024 x 1024 texture the
+// reference substitutes for formats it does not handle (loader.rs:35-44), with a warning.
 #include "frt_loader.hpp"
 #include <zlib.h>
 #include <cmath>
@@ -250,6 +252,252 @@ bool decode_png(const uint8_t* d, size_t n, std::vector<uint8_t>& px, uint32_t& 
     return true;
 }
 
+// ================================================================================================ JPEG (baseline)
+// Sequential Huffman JPEG, 8-bit, three components (what gltf's importer hands the reference as R8G8B8): ITU-T T.81 decoding,
+// float separable IDCT, libjpeg-style triangle ("fancy") chroma upsampling for 2x1 / 2x2 subsampling, JFIF YCbCr -> RGB.
+// Progressive / arithmetic / 12-bit / lossless files and 1- or 4-component images are reported as unsupported (the caller falls
+// back to the white texture); single-component (grey) JPEGs are exactly the case the reference itself rejects (Format::R8).
+namespace {
+struct JHuff {
+    uint8_t vals[256]; int maxcode[18], valptr[17], mincode[17]; bool present = false;
+    uint16_t fast[512];       // 9-bit lookahead: (length << 8) | symbol, 0 = longer code
+    void build(const uint8_t counts[16], const uint8_t* symbols, int n) {
+        present = true;
+        memcpy(vals, symbols, (size_t)n);
+        int code = 0, k = 0;
+        memset(fast, 0, sizeof fast);
+        for (int len = 1; len <= 16; ++len) {
+            valptr[len] = k; mincode[len] = code;
+            for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code)
+                if (len <= 9) for (int f = 0; f < (1 << (9 - len)); ++f) fast[(code << (9 - len)) | f] = (uint16_t)((len << 8) | vals[k]);
+            maxcode[len] = counts[len - 1] ? code - 1 : -1;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7FFFFFFF;
+    }
+};
+struct JBits {
+    const uint8_t* p; const uint8_t* e; uint32_t acc = 0; int n = 0; bool marker = false;
+    void fill() {
+        while (n <= 24) {
+            uint32_t b = 0;
+            if (!marker && p < e) {
+                b = *p;
+                if (b == 0xFF) {
+                    if (p + 1 < e && p[1] == 0x00) p += 2;          // stuffed zero
+                    else { marker = true; b = 0; }                   // a marker: feed zeros until the caller handles it
+                } else ++p;
+            }
+            acc |= b << (24 - n); n += 8;
+        }
+    }
+    int peek(int k) { fill(); return (int)(acc >> (32 - k)); }
+    void skip(int k) { acc <<= k; n -= k; }
+    int get(int k) { if (k == 0) return 0; int v = peek(k); skip(k); return v; }
+    void reset() { acc = 0; n = 0; marker = false; }
+};
+int jdecode(JBits& b, const JHuff& h) {
+    int look = b.peek(9);
+    uint16_t f = h.fast[look];
+    if (f) { b.skip(f >> 8); return f & 0xFF; }
+    int code = b.peek(16);
+    for (int len = 10; len <= 16; ++len) {
+        int c = code >> (16 - len);
+        if (h.maxcode[len] >= 0 && c <= h.maxcode[len] && c >= h.mincode[len]) { b.skip(len); return h.vals[h.valptr[len] + c - h.mincode[len]]; }
+    }
+    return -1;
+}
+int jextend(int v, int t) { return (t && v < (1 << (t - 1))) ? v - (1 << t) + 1 : v; }
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+struct JComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; int bw = 0, bh = 0; std::vector<uint8_t> plane; };
+
+void jidct(const float in[64], uint8_t* out, size_t pitch) {
+    static float c[8][8]; static bool init = false;
+    if (!init) { for (int x = 0; x < 8; ++x) for (int u = 0; u < 8; ++u) c[x][u] = (u == 0 ? 0.35355339059327379f : 0.5f) * cosf((2 * x + 1) * u * 3.14159265358979323846f / 16.0f); init = true; }
+    float tmp[64];
+    for (int v = 0; v < 8; ++v) for (int x = 0; x < 8; ++x) { float s = 0; for (int u = 0; u < 8; ++u) s += c[x][u] * in[v * 8 + u]; tmp[v * 8 + x] = s; }
+    for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) {
+        float s = 0; for (int v = 0; v < 8; ++v) s += c[y][v] * tmp[v * 8 + x];
+        s = floorf(s + 128.5f);
+        out[(size_t)y * pitch + x] = (uint8_t)(s < 0 ? 0 : (s > 255 ? 255 : s));
+    }
+}
+// plane (pw x ph) -> full resolution (fw x fh, fw = pw * fx, fh = ph * fy)
+void jupsample(const std::vector<uint8_t>& in, int pw, int ph, int fx, int fy, std::vector<uint8_t>& out) {
+    const int fw = pw * fx, fh = ph * fy;
+    out.resize((size_t)fw * fh);
+    if (fx == 1 && fy == 1) { out = in; return; }
+    if (fx == 2 && fy == 1) {
+        for (int y = 0; y < ph; ++y) {
+            const uint8_t* r = &in[(size_t)y * pw]; uint8_t* o = &out[(size_t)y * fw];
+            for (int x = 0; x < pw; ++x) {
+                int c = r[x], l = r[x > 0 ? x - 1 : 0], n = r[x + 1 < pw ? x + 1 : pw - 1];
+                o[2 * x] = (uint8_t)(x == 0 ? c : (3 * c + l + 1) >> 2);
+                o[2 * x + 1] = (uint8_t)(x + 1 == pw ? c : (3 * c + n + 2) >> 2);
+            }
+        }
+        return;
+    }
+    if (fx == 2 && fy == 2) {
+        std::vector<int> sum((size_t)pw);
+        for (int oy = 0; oy < fh; ++oy) {
+            int y0 = oy >> 1, y1 = (oy & 1) ? y0 + 1 : y0 - 1;
+            y1 = y1 < 0 ? 0 : (y1 >= ph ? ph - 1 : y1);
+            const uint8_t* a = &in[(size_t)y0 * pw]; const uint8_t* b = &in[(size_t)y1 * pw];
+            for (int x = 0; x < pw; ++x) sum[(size_t)x] = 3 * a[x] + b[x];
+            uint8_t* o = &out[(size_t)oy * fw];
+            for (int x = 0; x < pw; ++x) {
+                int t = sum[(size_t)x], l = sum[(size_t)(x > 0 ? x - 1 : 0)], n = sum[(size_t)(x + 1 < pw ? x + 1 : pw - 1)];
+                o[2 * x] = (uint8_t)(x == 0 ? (t * 4 + 8) >> 4 : (3 * t + l + 8) >> 4);
+                o[2 * x + 1] = (uint8_t)(x + 1 == pw ? (t * 4 + 7) >> 4 : (3 * t + n + 7) >> 4);
+            }
+        }
+        return;
+    }
+    for (int y = 0; y < fh; ++y) for (int x = 0; x < fw; ++x) out[(size_t)y * fw + x] = in[(size_t)(y / fy) * pw + x / fx];   // other ratios: replicate
+}
+} // namespace
+
+bool decode_jpeg(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, uint32_t& W, uint32_t& H, std::string& why) {
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) { why = "not a JPEG"; return false; }
+    uint16_t qt[4][64]; bool have_qt[4] = {false, false, false, false};
+    JHuff hdc[4], hac[4];
+    std::vector<JComp> comps;
+    int hmax = 1, vmax = 1, restart = 0, mcus_x = 0, mcus_y = 0;
+    bool have_sof = false, adobe = false; int adobe_transform = -1;
+    size_t pos = 2;
+    bool decoded_any = false;
+    while (pos + 4 <= n) {
+        if (d[pos] != 0xFF) { ++pos; continue; }
+        uint8_t m = d[pos + 1];
+        if (m == 0xFF) { ++pos; continue; }
+        pos += 2;
+        if (m == 0xD9) break;                                            // EOI
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;             // TEM, stray RSTn
+        if (pos + 2 > n) break;
+        size_t len = ((size_t)d[pos] << 8) | d[pos + 1];
+        if (len < 2 || pos + len > n) { why = "truncated JPEG segment"; return false; }
+        const uint8_t* s = d + pos + 2; size_t sl = len - 2;
+        if (m == 0xDB) {                                                  // DQT
+            size_t k = 0;
+            while (k < sl) {
+                int pq = s[k] >> 4, tq = s[k] & 15; ++k;
+                if (tq > 3 || k + (pq ? 128u : 64u) > sl) { why = "bad DQT"; return false; }
+                for (int i = 0; i < 64; ++i) { qt[tq][kZigzag[i]] = pq ? (uint16_t)((s[k] << 8) | s[k + 1]) : s[k]; k += pq ? 2 : 1; }
+                have_qt[tq] = true;
+            }
+        } else if (m == 0xC4) {                                           // DHT
+            size_t k = 0;
+            while (k + 17 <= sl) {
+                int tc = s[k] >> 4, th = s[k] & 15; ++k;
+                int total = 0; for (int i = 0; i < 16; ++i) total += s[k + i];
+                if (th > 3 || tc > 1 || total > 256 || k + 16 + (size_t)total > sl) { why = "bad DHT"; return false; }
+                (tc ? hac[th] : hdc[th]).build(s + k, s + k + 16, total);
+                k += 16 + (size_t)total;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {                              // SOF0 / SOF1: sequential Huffman
+            if (sl < 6 || s[0] != 8) { why = "JPEG precision other than 8 bits"; return false; }
+            H = ((uint32_t)s[1] << 8) | s[2]; W = ((uint32_t)s[3] << 8) | s[4];
+            int nf = s[5];
+            if (nf != 3) { why = std::to_string(nf) + "-component JPEG decodes to a format other than R8G8B8"; return false; }
+            if (W == 0 || H == 0 || W > 16384 || H > 16384 || sl < 6 + 3 * (size_t)nf) { why = "bad JPEG frame header"; return false; }
+            comps.assign((size_t)nf, JComp());
+            for (int i = 0; i < nf; ++i) {
+                comps[(size_t)i].id = s[6 + 3 * i]; comps[(size_t)i].h = s[7 + 3 * i] >> 4; comps[(size_t)i].v = s[7 + 3 * i] & 15; comps[(size_t)i].tq = s[8 + 3 * i] & 3;
+                if (comps[(size_t)i].h < 1 || comps[(size_t)i].h > 4 || comps[(size_t)i].v < 1 || comps[(size_t)i].v > 4) { why = "bad JPEG sampling factors"; return false; }
+                hmax = std::max(hmax, comps[(size_t)i].h); vmax = std::max(vmax, comps[(size_t)i].v);
+            }
+            mcus_x = (int)((W + 8u * (uint32_t)hmax - 1u) / (8u * (uint32_t)hmax)); mcus_y = (int)((H + 8u * (uint32_t)vmax - 1u) / (8u * (uint32_t)vmax));
+            for (JComp& c : comps) {
+                if (hmax % c.h || vmax % c.v) { why = "fractional JPEG sampling ratio"; return false; }
+                c.bw = mcus_x * c.h; c.bh = mcus_y * c.v; c.plane.assign((size_t)c.bw * 8 * (size_t)c.bh * 8, 128);
+            }
+            have_sof = true;
+        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+            why = m == 0xC2 ? "progressive JPEG (not decoded in this build)" : "JPEG process other than baseline (not decoded in this build)"; return false;
+        } else if (m == 0xDD) { if (sl >= 2) restart = (s[0] << 8) | s[1]; }
+        else if (m == 0xEE && sl >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
+        else if (m == 0xDA) {                                             // SOS + entropy-coded data
+            if (!have_sof || sl < 1) { why = "JPEG scan before frame header"; return false; }
+            int ns = s[0];
+            if (ns < 1 || ns > 3 || sl < 1 + 2 * (size_t)ns + 3) { why = "bad JPEG scan header"; return false; }
+            std::vector<JComp*> sc;
+            for (int i = 0; i < ns; ++i) {
+                JComp* c = nullptr;
+                for (JComp& k : comps) if (k.id == s[1 + 2 * i]) c = &k;
+                if (!c) { why = "JPEG scan names an unknown component"; return false; }
+                c->td = s[2 + 2 * i] >> 4; c->ta = s[2 + 2 * i] & 15;
+                if (c->td > 3 || c->ta > 3 || !hdc[c->td].present || !hac[c->ta].present || !have_qt[c->tq]) { why = "JPEG scan uses a missing table"; return false; }
+                c->pred = 0; sc.push_back(c);
+            }
+            JBits b; b.p = d + pos + len; b.e = d + n;
+            auto block = [&](JComp& c, int bx, int by) -> bool {
+                float coef[64]; for (float& f : coef) f = 0.0f;
+                int t = jdecode(b, hdc[c.td]);
+                if (t < 0 || t > 11) return false;
+                c.pred += jextend(b.get(t), t);
+                coef[0] = (float)(c.pred * (int)qt[c.tq][0]);
+                for (int k = 1; k < 64;) {
+                    int rs = jdecode(b, hac[c.ta]);
+                    if (rs < 0) return false;
+                    int r = rs >> 4, sz = rs & 15;
+                    if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                    k += r;
+                    if (k > 63) return false;
+                    int nat = kZigzag[k];
+                    coef[nat] = (float)(jextend(b.get(sz), sz) * (int)qt[c.tq][nat]);
+                    ++k;
+                }
+                jidct(coef, &c.plane[((size_t)by * 8) * ((size_t)c.bw * 8) + (size_t)bx * 8], (size_t)c.bw * 8);
+                return true;
+            };
+            int units_x, units_y;
+            if (ns == 1) {   // non-interleaved: the component's own block grid, clipped to the image
+                JComp& c = *sc[0];
+                units_x = (int)(((W * (uint32_t)c.h + (uint32_t)hmax - 1u) / (uint32_t)hmax + 7u) / 8u);
+                units_y = (int)(((H * (uint32_t)c.v + (uint32_t)vmax - 1u) / (uint32_t)vmax + 7u) / 8u);
+            } else { units_x = mcus_x; units_y = mcus_y; }
+            int count = 0, rst = 0;
+            for (int uy = 0; uy < units_y; ++uy) for (int ux = 0; ux < units_x; ++ux) {
+                if (restart && count == restart) {   // RSTn: byte-align, consume the marker, reset predictors
+                    b.reset();
+                    while (b.p + 1 < b.e && !(b.p[0] == 0xFF && b.p[1] >= 0xD0 && b.p[1] <= 0xD7)) ++b.p;
+                    if (b.p + 1 < b.e) b.p += 2;
+                    (void)rst; ++rst;
+                    for (JComp* c : sc) c->pred = 0;
+                    count = 0;
+                }
+                if (ns == 1) { if (!block(*sc[0], ux, uy)) { why = "corrupt JPEG entropy data"; return false; } }
+                else for (JComp* c : sc) for (int v = 0; v < c->v; ++v) for (int h = 0; h < c->h; ++h)
+                    if (!block(*c, ux * c->h + h, uy * c->v + v)) { why = "corrupt JPEG entropy data"; return false; }
+                ++count;
+            }
+            decoded_any = true;
+            // continue after the entropy-coded segment: the reader stopped at (or before) the next marker
+            pos = (size_t)(b.p - d);
+            while (pos + 1 < n && !(d[pos] == 0xFF && d[pos + 1] != 0x00 && !(d[pos + 1] >= 0xD0 && d[pos + 1] <= 0xD7) && d[pos + 1] != 0xFF)) ++pos;
+            continue;
+        }
+        pos += len;
+    }
+    if (!have_sof || !decoded_any) { why = "JPEG without image data"; return false; }
+    std::vector<uint8_t> full[3];
+    const int fw = mcus_x * hmax * 8;
+    for (int i = 0; i < 3; ++i) jupsample(comps[(size_t)i].plane, comps[(size_t)i].bw * 8, comps[(size_t)i].bh * 8, hmax / comps[(size_t)i].h, vmax / comps[(size_t)i].v, full[i]);
+    rgb.resize((size_t)W * H * 3);
+    const bool is_rgb = adobe && adobe_transform == 0;
+    for (uint32_t y = 0; y < H; ++y) for (uint32_t x = 0; x < W; ++x) {
+        size_t k = (size_t)y * (size_t)fw + x;
+        float Y = full[0][k], cb = (float)full[1][k] - 128.0f, cr = (float)full[2][k] - 128.0f;
+        float r = is_rgb ? Y : Y + 1.402f * cr, g = is_rgb ? (float)full[1][k] : Y - 0.344136f * cb - 0.714136f * cr, bl = is_rgb ? (float)full[2][k] : Y + 1.772f * cb;
+        auto q = [](float v) { v = floorf(v + 0.5f); return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+        uint8_t* o = &rgb[((size_t)y * W + x) * 3];
+        o[0] = q(r); o[1] = q(g); o[2] = q(bl);
+    }
+    return true;
+}
+
 // ================================================================================================ Lanczos3 resize
 namespace {
 float sinc_(float t) { float a = t * 3.14159265358979323846f; return t == 0.0f ? 1.0f : sinf(a) / a; }   // image: imageops/sample.rs sinc
@@ -382,9 +630,9 @@ bool decode_image(const Doc& d, const JVal& img, std::vector<uint8_t>& rgba, uin
         if (off > B.size() || len > B.size() - off) { why = "image bufferView exceeds its buffer"; return false; }
         bytes.assign(B.begin() + (long)off, B.begin() + (long)(off + len));
     }
-    if (bytes.size() >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8) { why = "JPEG image (no JPEG decoder in this build)"; return false; }
     std::vector<uint8_t> px; uint32_t ch = 0;
-    if (!decode_png(bytes.data(), bytes.size(), px, w, h, ch, why)) return false;
+    if (bytes.size() >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8) { if (!decode_jpeg(bytes.data(), bytes.size(), px, w, h, why)) return false; ch = 3; }
+    else if (!decode_png(bytes.data(), bytes.size(), px, w, h, ch, why)) return false;
     rgba.resize((size_t)w * h * 4);
     for (size_t i = 0, n = (size_t)w * h; i < n; ++i) {   // DynamicImage::to_rgba8: RGB -> alpha 255
         rgba[i * 4] = px[i * ch]; rgba[i * 4 + 1] = px[i * ch + 1]; rgba[i * 4 + 2] = px[i * ch + 2]; rgba[i * 4 + 3] = ch == 4 ? px[i * 4 + 3] : 255;

@@ -130,10 +130,10 @@ def test_png_colour_key_and_each_filter(frt, tmp_path):
 
 
 def test_unsupported_images_become_white_with_a_warning(frt, tmp_path):
-    """loader.rs:35-44: formats other than R8G8B8 / R8G8B8A8 -> white TEXTURE_WIDTH x TEXTURE_HEIGHT; JPEG is not decoded here."""
+    """loader.rs:35-44: formats other than R8G8B8 / R8G8B8A8 -> white TEXTURE_WIDTH x TEXTURE_HEIGHT; so do undecodable files."""
     g = np.zeros((8, 8), np.uint8)
     cases = {"grey": _gltf.png_bytes(g, grey=True), "sixteen": _gltf.png_bytes(np.zeros((4, 4, 3), np.uint8), sixteen=True),
-             "jpeg": b"\xff\xd8\xff\xe0" + b"\0" * 32, "junk": b"not an image at all"}
+             "jpeg": b"\xff\xd8\xff\xe0\x00\x10" + b"\0" * 32, "junk": b"not an image at all"}
     for name, data in cases.items():
         m = frt.loader.load_gltf(_one_image_model(tmp_path, data, name + ".glb"))
         assert (m.image(0) == 255).all(), name
@@ -280,3 +280,43 @@ f -4/1 -1/2 -5/3 -8/4
     assert (g2.attributes[:, 0:2] == frt.geometry.encode_octahedral_normal([0, 1, 0])).all() and (g2.attributes[:, 2:4] == 0).all()
     with pytest.raises(frt.FrtError):
         (tmp_path / "e.obj").write_text("v 0 0 0\n"); frt.loader.load_gltf(tmp_path / "e.obj")
+
+
+@pytest.mark.parametrize("subsampling,quality,extra", [(0, 92, {}), (1, 85, {}), (2, 75, {}), (2, 90, {"restart_marker_rows": 1}), (0, 95, {"optimize": True})])
+def test_baseline_jpeg_textures(frt, tmp_path, subsampling, quality, extra):
+    """Baseline JPEG (4:4:4, 4:2:2, 4:2:0, restart markers, optimised Huffman tables) against Pillow's libjpeg decode of the same
+    bytes. The standard does not fix IDCT rounding or chroma upsampling, so decoders differ by a level here and there."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    img = _gltf.make_textures()[0][..., :3]
+    buf = io.BytesIO()
+    try:
+        PIL.fromarray(img).save(buf, "JPEG", quality=quality, subsampling=subsampling, **extra)
+    except TypeError:
+        pytest.skip("this Pillow cannot write the requested JPEG variant")
+    data = buf.getvalue()
+    want = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB")).astype(np.int32)
+    m = frt.loader.load_gltf(_one_image_model(tmp_path, data))
+    assert m.warnings() == []
+    got = m.image(0)
+    assert (got[..., 3] == 255).all()
+    d = np.abs(got[..., :3].astype(np.int32) - want)
+    assert d.mean() < 0.6 and d.max() <= 6, (d.mean(), d.max())
+
+
+def test_jpeg_variants_the_loader_does_not_decode(frt, tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    img = _gltf.make_textures()[0][:64, :64, :3]
+    for name, kw, conv in (("progressive", {"progressive": True}, "RGB"), ("grey", {}, "L")):
+        buf = io.BytesIO(); PIL.fromarray(img).convert(conv).save(buf, "JPEG", quality=90, **kw)
+        m = frt.loader.load_gltf(_one_image_model(tmp_path, buf.getvalue(), name + ".glb"))
+        assert (m.image(0) == 255).all() and len(m.warnings()) == 1 and "white" in m.warnings()[0], name
+    # odd size + resize path
+    odd = _gltf.make_textures()[0][:333, :517, :3]
+    buf = io.BytesIO(); PIL.fromarray(odd).save(buf, "JPEG", quality=90, subsampling=2)
+    m = frt.loader.load_gltf(_one_image_model(tmp_path, buf.getvalue(), "odd.glb"))
+    want = np.asarray(PIL.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+    want = _gltf.lanczos3_resize(np.concatenate([want, np.full(want.shape[:2] + (1,), 255, np.uint8)], axis=2), 1024, 1024).astype(np.int32)
+    d = np.abs(m.image(0).astype(np.int32) - want)
+    assert m.warnings() == [] and d.mean() < 0.6 and d.max() <= 8, (d.mean(), d.max())
