@@ -201,7 +201,7 @@ bool decode_png(const uint8_t* d, size_t n, std::vector<uint8_t>& px, uint32_t& 
         else if (!memcmp(tag, "IEND", 4)) done = true;
         pos += 12 + (size_t)len;
     }
-    if (!have_ihdr || w == 0 || h == 0 || w > 16384 || h > 16384) { why = "bad PNG header"; return false; }
+    if (!have_ihdr || w == 0 || h == 0 || w > 16384 || h > 16384 || (uint64_t)w * h > (1ull << 26)) { why = "bad or oversized PNG header"; return false; }
     if (interlace) { why = "interlaced PNG (not decoded in this build)"; return false; }
     uint32_t src_ch;
     if (ctype == 2 && depth == 8) src_ch = 3;
@@ -261,19 +261,23 @@ namespace {
 struct JHuff {
     uint8_t vals[256]; int maxcode[18], valptr[17], mincode[17]; bool present = false;
     uint16_t fast[512];       // 9-bit lookahead: (length << 8) | symbol, 0 = longer code
-    void build(const uint8_t counts[16], const uint8_t* symbols, int n) {
-        present = true;
+    bool build(const uint8_t counts[16], const uint8_t* symbols, int n) {
+        present = false;
         memcpy(vals, symbols, (size_t)n);
         int code = 0, k = 0;
         memset(fast, 0, sizeof fast);
         for (int len = 1; len <= 16; ++len) {
             valptr[len] = k; mincode[len] = code;
-            for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code)
+            for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
+                if (code >= (1 << len)) return false;            // over-subscribed table
                 if (len <= 9) for (int f = 0; f < (1 << (9 - len)); ++f) fast[(code << (9 - len)) | f] = (uint16_t)((len << 8) | vals[k]);
+            }
             maxcode[len] = counts[len - 1] ? code - 1 : -1;
             code <<= 1;
         }
         maxcode[17] = 0x7FFFFFFF;
+        present = true;
+        return true;
     }
 };
 struct JBits {
@@ -393,7 +397,7 @@ bool decode_jpeg(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, uint32_t
                 int tc = s[k] >> 4, th = s[k] & 15; ++k;
                 int total = 0; for (int i = 0; i < 16; ++i) total += s[k + i];
                 if (th > 3 || tc > 1 || total > 256 || k + 16 + (size_t)total > sl) { why = "bad DHT"; return false; }
-                (tc ? hac[th] : hdc[th]).build(s + k, s + k + 16, total);
+                if (!(tc ? hac[th] : hdc[th]).build(s + k, s + k + 16, total)) { why = "bad DHT"; return false; }
                 k += 16 + (size_t)total;
             }
         } else if (m == 0xC0 || m == 0xC1) {                              // SOF0 / SOF1: sequential Huffman
@@ -401,7 +405,7 @@ bool decode_jpeg(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, uint32_t
             H = ((uint32_t)s[1] << 8) | s[2]; W = ((uint32_t)s[3] << 8) | s[4];
             int nf = s[5];
             if (nf != 3) { why = std::to_string(nf) + "-component JPEG decodes to a format other than R8G8B8"; return false; }
-            if (W == 0 || H == 0 || W > 16384 || H > 16384 || sl < 6 + 3 * (size_t)nf) { why = "bad JPEG frame header"; return false; }
+            if (W == 0 || H == 0 || W > 16384 || H > 16384 || (uint64_t)W * H > (1ull << 26) || sl < 6 + 3 * (size_t)nf) { why = "bad or oversized JPEG frame header"; return false; }
             comps.assign((size_t)nf, JComp());
             for (int i = 0; i < nf; ++i) {
                 comps[(size_t)i].id = s[6 + 3 * i]; comps[(size_t)i].h = s[7 + 3 * i] >> 4; comps[(size_t)i].v = s[7 + 3 * i] & 15; comps[(size_t)i].tq = s[8 + 3 * i] & 3;
@@ -580,6 +584,7 @@ bool get_accessor(const Doc& d, long long index, Acc& a, std::vector<uint8_t>& z
     if (esz == 0) { err = "accessor with unknown component or element type"; return false; }
     long long bv = j.integer("bufferView", -1);
     if (bv < 0) {   // glTF: an accessor without a bufferView is all zeros
+        if (a.count > (1u << 28)) { err = "accessor without bufferView is too large"; return false; }
         zeros.assign(esz * a.count, 0); a.base = zeros.data(); a.stride = esz; return true;
     }
     const auto& views = d.root.arr("bufferViews");
@@ -591,7 +596,7 @@ bool get_accessor(const Doc& d, long long index, Acc& a, std::vector<uint8_t>& z
     size_t voff = (size_t)v.integer("byteOffset", 0), vlen = (size_t)v.integer("byteLength", 0), aoff = (size_t)j.integer("byteOffset", 0);
     size_t stride = (size_t)v.integer("byteStride", 0); if (stride == 0) stride = esz;
     if (voff > B.size() || vlen > B.size() - voff) { err = "bufferView exceeds its buffer"; return false; }
-    if (a.count && (aoff > vlen || (a.count - 1) * stride + esz > vlen - aoff)) { err = "accessor exceeds its bufferView"; return false; }
+    if (a.count && (aoff > vlen || a.count > vlen || stride > vlen || (a.count - 1) * stride + esz > vlen - aoff)) { err = "accessor exceeds its bufferView"; return false; }
     a.base = B.data() + voff + aoff; a.stride = stride;
     return true;
 }

@@ -320,3 +320,35 @@ def test_jpeg_variants_the_loader_does_not_decode(frt, tmp_path):
     want = _gltf.lanczos3_resize(np.concatenate([want, np.full(want.shape[:2] + (1,), 255, np.uint8)], axis=2), 1024, 1024).astype(np.int32)
     d = np.abs(m.image(0).astype(np.int32) - want)
     assert m.warnings() == [] and d.mean() < 0.6 and d.max() <= 8, (d.mean(), d.max())
+
+
+def test_loader_survives_mutated_files(frt, tmp_path):
+    """Robustness: truncated and bit-flipped GLB / PNG / JPEG inputs must end in a clean error or a fallback, never a crash."""
+    path, _ = _sphere_model(tmp_path, frt)
+    blob = bytearray(path.read_bytes()[:400000])           # keep the test quick: JSON chunk + geometry + part of the first image
+    rng = np.random.default_rng(11)
+    survived = 0
+    for trial in range(60):
+        b = bytearray(blob)
+        if trial % 3 == 0:
+            b = b[:int(rng.integers(12, len(b)))]
+        else:
+            for _ in range(int(rng.integers(1, 30))):
+                b[int(rng.integers(0, min(len(b), 3000)))] = int(rng.integers(0, 256))     # the JSON / header region
+        p = tmp_path / f"m{trial}.glb"; p.write_bytes(bytes(b))
+        try:
+            frt.loader.load_gltf(p).counts(); survived += 1
+        except frt.FrtError:
+            pass
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    buf = io.BytesIO(); PIL.fromarray(_gltf.make_textures()[0][:96, :96, :3]).save(buf, "JPEG", quality=80)
+    jp = buf.getvalue(); pn = _gltf.png_bytes(_gltf.make_textures()[0][:64, :64])
+    for trial in range(80):
+        src = bytearray(jp if trial % 2 else pn)
+        for _ in range(int(rng.integers(1, 12))):
+            src[int(rng.integers(2, len(src)))] = int(rng.integers(0, 256))
+        if trial % 5 == 0:
+            src = src[:int(rng.integers(8, len(src)))]
+        m = frt.loader.load_gltf(_one_image_model(tmp_path, bytes(src), f"i{trial}.glb"))
+        assert m.image(0).shape == (1024, 1024, 4)
