@@ -562,4 +562,10 @@ int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
     return FRT_OK;
 }
 
+int frt_renderer_set_timing(frt_renderer* r, int on) {
+    if (!r) return fail(FRT_ERR_INVALID_ARG, "set_timing: null");
+    if (on) r->flags |= FRT_FLAG_TIMING; else r->flags &= ~FRT_FLAG_TIMING;
+    return FRT_OK;
+}
+
 } // extern "C"

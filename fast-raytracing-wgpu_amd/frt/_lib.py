@@ -108,6 +108,7 @@ SYMBOLS = {
     "frt_renderer_buffer_info": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_U32)]),
     "frt_renderer_phase_rows": (C.c_int, [_P, _P]),
     "frt_renderer_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "frt_renderer_set_timing": (C.c_int, [_P, C.c_int]),
 }
 
 _lib = None

@@ -94,6 +94,9 @@ class Renderer:
         v = list(r)
         return {"gbuffer": (v[0], v[1]), "temporal": (v[2], v[3]), "spatial": (v[4], v[5]), "post": (v[6], v[7])}
 
+    def set_timing(self, on):
+        check(lib().frt_renderer_set_timing(self._h, 1 if on else 0))
+
     def stats(self):
         s = Stats()
         check(lib().frt_renderer_stats(self._h, C.byref(s)))

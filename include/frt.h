@@ -214,6 +214,8 @@ int frt_renderer_buffer_info(const frt_renderer* r, int buf, int index, void** d
 /* Rows this renderer computes per phase given its strip: out[0..1] gbuffer, [2..3] temporal, [4..5] spatial, [6..7] post */
 int frt_renderer_phase_rows(const frt_renderer* r, uint32_t out[8]);
 int frt_renderer_stats(frt_renderer* r, frt_stats* out);      /* syncs first */
+/* Switch FRT_FLAG_TIMING on or off after creation (the per-stage HIP events cost ~25 us per frame: too much for a thin strip) */
+int frt_renderer_set_timing(frt_renderer* r, int on);
 
 #ifdef __cplusplus
 }
