@@ -352,3 +352,30 @@ def test_loader_survives_mutated_files(frt, tmp_path):
             src = src[:int(rng.integers(8, len(src)))]
         m = frt.loader.load_gltf(_one_image_model(tmp_path, bytes(src), f"i{trial}.glb"))
         assert m.image(0).shape == (1024, 1024, 4)
+
+
+def test_gltf_showcase_scenes(frt, tmp_path):
+    """scenes.rs:324-520 wrappers (assets are not shipped: the synthetic model stands in). Transforms as glam composes them."""
+    path, ref = _sphere_model(tmp_path, frt)
+    s = frt.scenes.create_avocado_scene(path)
+    inst = s.get("instances")
+    M = inst[2, 5:21].view(np.float32).reshape(4, 4)
+    assert np.allclose(M, np.diag([20, 20, 20, 1]).astype(np.float32))
+    L = inst[1, 5:21].view(np.float32).reshape(4, 4)                  # translate(0,5,0) * rotation_x(pi): the light faces down
+    assert L[3, 1] == 5.0 and abs(L[1, 1] + 1.0) < 1e-6 and abs(L[2, 2] + 1.0) < 1e-6
+    light = frt.Light.from_buffer_copy(s.get("lights")[0].tobytes())
+    assert abs(light.position[1] - 5.0) < 1e-6
+    h = frt.scenes.create_damaged_helmet_scene(path).get("instances")[2, 5:21].view(np.float32).reshape(4, 4)
+    assert abs(h[1, 2] - 1.0) < 1e-6 and abs(h[2, 1] + 1.0) < 1e-6    # rotation_x(pi/2): +Y -> +Z
+    v = frt.scenes.create_multi_material_model_scene(path).get("instances")[2, 5:21].view(np.float32).reshape(4, 4)
+    assert abs(v[0, 0] + 0.5) < 1e-6 and abs(v[2, 2] + 0.5) < 1e-6 and v[1, 1] == 0.5
+    c = frt.scenes.create_chocolate_truffle_scene(path)
+    n = c.counts()
+    assert n["lights"] == 3 and n["meshes"] == 2 + 3 + 1 and n["instances"] == 1 + 3 + 3 and n["materials"] == 1 + 2 + 3
+    mats = [frt.Material.from_buffer_copy(r.tobytes()) for r in c.get("materials")]
+    assert mats[0].metallic == 1.0 and mats[0].roughness == np.float32(0.8)             # Material::metallic(0.8) quirk
+    assert mats[1].roughness == np.float32(0.25) and mats[2].roughness == np.float32(0.25)   # both bright: satin, metallic left at 1
+    lights = [frt.Light.from_buffer_copy(r.tobytes()) for r in c.get("lights")]
+    assert [l.type_ for l in lights] == [1, 1, 1] and list(lights[0].position) == [8.0, 4.0, 2.0] and lights[0].emission[3] == 80.0
+    fb = frt.scenes.create_chocolate_truffle_scene(tmp_path / "missing.glb", fallback=path)   # falls back to the avocado scene
+    assert fb.counts()["lights"] == 1
