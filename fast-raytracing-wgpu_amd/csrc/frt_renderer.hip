@@ -41,6 +41,7 @@ struct frt_renderer {
     hipStream_t side = nullptr;            // FRT_FLAG_OVERLAP_POST: the post stage runs here
     hipEvent_t ev_spatial = nullptr, ev_post = nullptr, ev_smain = nullptr, ev_scont = nullptr;
     bool post_in_flight = false, scont_in_flight = false;
+    uint32_t motion_slot = 0;             // which motion buffer the last G-buffer stage wrote (ping-pong under the side-stream schedule)
     uint32_t W = 0, H = 0, max_depth = 8, rb = 0, re = 0, flags = 0, motion_halo = 0;
     uint32_t frame_count = 0;
     SceneView sv{};
@@ -395,6 +396,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
     HIP_TRY(hipSetDevice(r->device));
     FrameView fv;
     fill_frame_view(r, cam, fv);
+    if (phases & FRT_PHASE_GBUFFER) r->motion_slot = (r->side && (r->frame_count & 1u)) ? 1u : 0u;
     uint32_t rows[8];
     phase_rows(r, rows);
     for (int stage = 0; stage < 4; ++stage) {
@@ -470,6 +472,14 @@ int frt_renderer_sync(frt_renderer* r) {
 uint32_t frt_renderer_frame_count(const frt_renderer* r) { return r ? r->frame_count : 0u; }
 int frt_renderer_reset(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "reset: null");
+    // The side-stream schedule relies on the ping-pong slots alternating from frame to frame; a reset breaks the alternation (the
+    // next frame may write the slot the in-flight tail of the last frame still reads), so the main stream first waits for that tail.
+    // Stream-level only: the reference resets every frame while the camera moves (state.rs:152), this must stay asynchronous.
+    if (r->side) {
+        HIP_TRY(hipSetDevice(r->device));
+        if (r->scont_in_flight) { HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_scont, 0)); r->scont_in_flight = false; }
+        if (r->post_in_flight) { HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0)); r->post_in_flight = false; }
+    }
     r->frame_count = 0;
     return FRT_OK;
 }
@@ -487,12 +497,12 @@ int frt_renderer_clear(frt_renderer* r) {
     return FRT_OK;
 }
 
-static int buf_index(int buf, int index) {
+static int buf_index(const frt_renderer* r, int buf, int index) {
     switch (buf) {
     case FRT_BUF_GPOS: return B_GPOS0 + (index & 1);
     case FRT_BUF_GNORMAL: return B_GNRM0 + (index & 1);
     case FRT_BUF_GALBEDO: return B_GALB0 + (index & 1);
-    case FRT_BUF_GMOTION: return (index & 1) ? B_GMOT1 : B_GMOT;
+    case FRT_BUF_GMOTION: return ((r->motion_slot ^ (uint32_t)index) & 1u) ? B_GMOT1 : B_GMOT;   // 0 = the last rendered frame's (the reference has one)
     case FRT_BUF_RESERVOIR: return B_RES0 + (index & 1);
     case FRT_BUF_RAW: return B_RAW;
     case FRT_BUF_DISPLAY: return B_DISP;
@@ -501,14 +511,14 @@ static int buf_index(int buf, int index) {
     return -1;
 }
 int frt_renderer_buffer_info(const frt_renderer* r, int buf, int index, void** device_ptr, uint32_t* bpp) {
-    int b = r ? buf_index(buf, index) : -1;
+    int b = r ? buf_index(r, buf, index) : -1;
     if (b < 0) return fail(FRT_ERR_INVALID_ARG, "buffer_info: bad buffer");
     if (device_ptr) *device_ptr = r->buf(b);
     if (bpp) *bpp = kBpp[b];
     return FRT_OK;
 }
 int frt_renderer_read_buffer(frt_renderer* r, int buf, int index, void* out) {
-    int b = r ? buf_index(buf, index) : -1;
+    int b = r ? buf_index(r, buf, index) : -1;
     if (b < 0 || !out) return fail(FRT_ERR_INVALID_ARG, "read_buffer: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
     { int rc_ = sync_all(r); if (rc_) return rc_; }
@@ -516,7 +526,7 @@ int frt_renderer_read_buffer(frt_renderer* r, int buf, int index, void* out) {
     return FRT_OK;
 }
 int frt_renderer_read_rows(frt_renderer* r, int buf, int index, uint32_t y0, uint32_t y1, void* out) {
-    int b = r ? buf_index(buf, index) : -1;
+    int b = r ? buf_index(r, buf, index) : -1;
     if (b < 0 || !out || y0 > y1 || y1 > r->H) return fail(FRT_ERR_INVALID_ARG, "read_rows: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
     { int rc_ = sync_all(r); if (rc_) return rc_; }
@@ -525,7 +535,7 @@ int frt_renderer_read_rows(frt_renderer* r, int buf, int index, uint32_t y0, uin
     return FRT_OK;
 }
 int frt_renderer_write_rows(frt_renderer* r, int buf, int index, uint32_t y0, uint32_t y1, const void* in) {
-    int b = r ? buf_index(buf, index) : -1;
+    int b = r ? buf_index(r, buf, index) : -1;
     if (b < 0 || !in || y0 > y1 || y1 > r->H) return fail(FRT_ERR_INVALID_ARG, "write_rows: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
     { int rc_ = sync_all(r); if (rc_) return rc_; }

@@ -172,7 +172,8 @@ enum {
     FRT_BUF_GPOS = 0,        /* rgba32f  16 B/px, x2 ping-pong */
     FRT_BUF_GNORMAL = 1,     /* rgba32f  16 B/px, x2 */
     FRT_BUF_GALBEDO = 2,     /* rgba8    4 B/px, x2 */
-    FRT_BUF_GMOTION = 3,     /* rg32f    8 B/px (slot 0; x2 ping-pong under FRT_FLAG_OVERLAP_POST) */
+    FRT_BUF_GMOTION = 3,     /* rg32f    8 B/px; index 0 = the last rendered frame (the reference has one motion texture); under
+                                FRT_FLAG_OVERLAP_POST there are two slots internally and index 1 is the other one */
     FRT_BUF_RESERVOIR = 4,   /* 32 B/px, [0] temporal result, [1] spatial result */
     FRT_BUF_RAW = 5,         /* rgba16f  8 B/px */
     FRT_BUF_DISPLAY = 6,     /* rgba8    4 B/px */

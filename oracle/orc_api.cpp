@@ -125,7 +125,8 @@ void* orc_renderer_create(void* scene, uint32_t w, uint32_t h, uint32_t max_dept
     return new Renderer((Scene*)scene, w, h, max_depth, use_bvh != 0, nthreads);
 }
 void orc_renderer_destroy(void* r) { delete (Renderer*)r; }
-void orc_renderer_reset(void* r) { ((Renderer*)r)->reset(); }
+void orc_renderer_reset(void* r) { ((Renderer*)r)->reset(); }                   // zero every buffer and the counter
+void orc_renderer_restart_counter(void* r) { ((Renderer*)r)->frame_count = 0; }   // src/state.rs:152: only renderer.frame_count = 0
 void orc_renderer_render(void* r, const void* cam288) { CameraUniform c; memcpy(&c, cam288, 288); ((Renderer*)r)->render(c); }
 void orc_renderer_render_phases(void* r, const void* cam288, int phases, uint32_t y0, uint32_t y1) {
     CameraUniform c; memcpy(&c, cam288, 288); ((Renderer*)r)->render_phases(c, phases, y0, y1);

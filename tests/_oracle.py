@@ -26,7 +26,7 @@ class Oracle:
             "orc_trace_closest": (None, [P, C.c_int, U32, P, P, C.c_float, C.c_float, P, P, P, P, P]),
             "orc_trace_any": (None, [P, C.c_int, U32, P, P, C.c_float, P, P]),
             "orc_renderer_create": (P, [P, U32, U32, U32, C.c_int, C.c_int]), "orc_renderer_destroy": (None, [P]),
-            "orc_renderer_reset": (None, [P]), "orc_renderer_render": (None, [P, P]),
+            "orc_renderer_reset": (None, [P]), "orc_renderer_restart_counter": (None, [P]), "orc_renderer_render": (None, [P, P]),
             "orc_renderer_render_phases": (None, [P, P, C.c_int, U32, U32]), "orc_renderer_end_frame": (None, [P]),
             "orc_renderer_frame_count": (U32, [P]), "orc_renderer_read": (C.c_int, [P, C.c_int, C.c_int, P]),
             "orc_renderer_write_rows": (C.c_int, [P, C.c_int, C.c_int, U32, U32, P]),
@@ -127,6 +127,9 @@ class OrcRenderer:
     @property
     def frame_count(self):
         return self.L.orc_renderer_frame_count(self.h)
+
+    def restart_counter(self):      # state.rs:152
+        self.L.orc_renderer_restart_counter(self.h)
 
     def read(self, buf, index=0):
         out = np.zeros((self.hgt, self.w, BPP[buf]), np.uint8)

@@ -274,3 +274,24 @@ def test_moving_camera_strips_equal_whole_image(gpu):
             with pytest.raises(RuntimeError):
                 for s in strips: check_halo(s)
     assert whole.stats()["halo_overflow"] == 0
+
+
+@pytest.mark.parametrize("flags", [0, 8], ids=["plain", "side-stream"])
+def test_reset_every_frame_like_a_moving_reference_camera(gpu, orc, flags):
+    """state.rs:152 sets frame_count = 0 on every frame in which the camera moved, so the ping-pong slots stop alternating. The
+    side-stream schedule must survive that (reset orders the main stream behind the in-flight tail)."""
+    frt = gpu
+    import _scenes
+    W, H = 160, 96
+    fs = frt.scenes.create_cornell_box()
+    os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    r = frt.Renderer(fs, W, H, flags=flags)
+    ro = os_.renderer(W, H, 8, True, 16)
+    cams = _scenes.moving_camera_uniforms(frt, W / H, 2, 7)
+    for f, cam in enumerate(cams):
+        if f in (2, 3, 4, 6):          # "camera moved": restart the counter, as the reference does
+            r.reset(); ro.restart_counter()
+        cam.frame_count = r.frame_count
+        r.render(cam); ro.render(cam)
+        compare_all(r.read_buffer, ro.read, f, f"reset sequence, flags {flags}")
+        assert r.frame_count == ro.frame_count
