@@ -190,3 +190,54 @@ def gltf_scene(frt, orc, path, model_transform, light_transform):
     osc = OrcScene(orc, oh)
     osc.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
     return fs, osc
+
+
+def random_scene(frt, orc, seed):
+    """A closed room with randomly placed, rotated and (sometimes mirrored) cubes / icospheres / crystals in random diffuse, glossy,
+    metal, glass and textured materials, a quad light and up to two sphere lights: material / lobe / light-type combinations the two
+    named scenes do not contain. Deterministic in `seed`."""
+    rng = np.random.default_rng(seed)
+    b = DualBuilder(frt, orc)
+    plane = b.add_mesh(*_geo(frt, "create_plane"))
+    shapes = [b.add_mesh(*_geo(frt, "create_cube")), b.add_mesh(*_geo(frt, "create_sphere", 2)), b.add_mesh(*_geo(frt, "create_crystal"))]
+    sphere = shapes[1]
+
+    def material(kind):
+        m = frt.material_new([float(x) for x in rng.uniform(0.15, 0.95, 3)] + [1.0])
+        if kind == "diffuse": m.roughness = float(rng.uniform(0.3, 1.0))
+        elif kind == "glossy": m.roughness = float(rng.uniform(0.06, 0.3))
+        elif kind == "metal": m.metallic = 1.0; m.roughness = float(rng.uniform(0.02, 0.5))
+        elif kind == "glass": m.metallic = 0.0; m.roughness = 0.0; m.ior = float(rng.uniform(1.3, 1.7)); m.transmission = 1.0
+        elif kind == "checker": m.roughness = float(rng.uniform(0.4, 1.0)); m.tex_info_0 = 0xFFFF0001
+        return m
+    kinds = ["diffuse", "glossy", "metal", "glass", "checker", "diffuse"]
+    mats = [b.add_material(material(k)) for k in kinds]
+    walls = [b.add_material(material("diffuse")) for _ in range(3)] + [b.add_material(material("checker"))]
+    ref = frt.scenes.create_cornell_box().get("instances")
+    for k in range(5):
+        b.add_instance(plane, walls[int(rng.integers(0, len(walls)))], ref[k, 5:21].view(np.float32))
+    # lights: the Cornell quad light + 0..2 small sphere lights
+    lights = 0
+    b.add_instance(plane, b.add_material(_emissive(frt, lights, (1, 1, 1), 10.0)), ref[5, 5:21].view(np.float32))
+    b.add_light(_quad_light(frt, (0, 0.99, 0), 0.25, (1, 1, 1, 10))); lights += 1
+    for _ in range(int(rng.integers(0, 3))):
+        pos = [float(x) for x in rng.uniform(-0.6, 0.6, 3)]
+        radius = float(np.float32(rng.uniform(0.03, 0.08)))
+        rgb = [float(x) for x in rng.uniform(0.05, 1.0, 3)]
+        l = frt.Light()
+        l.position[:] = pos; l.type_ = 1; l.u[:] = (0, 0, 0); l.v[:] = (radius, 0, 0)
+        l.area = float(np.float32(4.0 * np.pi) * np.float32(radius) * np.float32(radius)); l.emission[:] = rgb + [12.0]
+        b.add_instance(sphere, b.add_material(_emissive(frt, lights, rgb, 12.0)), _mat(*pos, 2 * radius, 2 * radius, 2 * radius))
+        b.add_light(l); lights += 1
+    for _ in range(7):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        s = rng.uniform(0.15, 0.45, 3)
+        if rng.random() < 0.25: s[0] = -s[0]                       # mirrored instance: front faces flip (frt_scene.hpp InstanceRec.flip)
+        M = np.eye(4); M[:3, :3] = R * s[None, :]; M[:3, 3] = rng.uniform(-0.6, 0.6, 3) * (1, 0.8, 1)
+        b.add_instance(shapes[int(rng.integers(0, 3))], mats[int(rng.integers(0, len(mats)))], np.asarray(M.T, np.float32).reshape(16))
+    fs, os_ = b.build()
+    return fs, os_, lights

@@ -92,3 +92,35 @@ def test_textured_gltf_scene_on_gpu(frt, orc, tmp_path):
     assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
     acc = r.read_accum()
     assert acc[..., :3].mean() > 0.01 and not np.isnan(acc).any()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_scenes_host_parity(frt, orc, hostcheck, seed):
+    fs, os_, nl = _scenes.random_scene(frt, orc, seed)
+    for k in ("tris", "tri_instance", "materials", "lights", "instances"):
+        assert fs.get(k).tobytes() == os_.get(k).tobytes(), k
+    W, H = 64, 48
+    ro = os_.renderer(W, H, 8, True, 8); rh = hostcheck.renderer(fs, W, H, 8, 8, state_machine=3 if seed == 2 else 0)
+    for f in range(3):
+        cam = frt.CameraController().build_uniform(W / H, f, nl)
+        ro.render(cam); rh.render(cam)
+        compare_all(rh.read, ro.read, f, f"random scene {seed}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_random_scenes_on_gpu(frt, orc, seed):
+    if frt.lib().frt_device_count() < 1:
+        pytest.fail("no HIP device")
+    fs, os_, nl = _scenes.random_scene(frt, orc, seed)
+    W, H, depth = 176, 99, 8 if seed % 2 else 12
+    r = frt.Renderer(fs, W, H, max_depth=depth, flags=frt.FLAG_OVERLAP_POST if seed % 3 == 0 else 0)
+    ro = os_.renderer(W, H, depth, True, 16)
+    cams = _scenes.moving_camera_uniforms(frt, W / H, nl, 4) if seed in (4, 8) else [frt.CameraController().build_uniform(W / H, f, nl) for f in range(4)]
+    for f, cam in enumerate(cams):
+        r.render(cam); ro.render(cam)
+        compare_all(r.read_buffer, ro.read, f, f"random scene {seed}")
+    st, so = r.stats(), ro.stats()["total"]
+    assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
+    acc = r.read_accum()
+    assert acc[..., :3].mean() > 0.005
