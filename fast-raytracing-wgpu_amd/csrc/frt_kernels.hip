@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(kBlock) post_kernel(FrameView fv) {
 static dim3 grid_for(const FrameView& fv) { return dim3((fv.W + 15u) / 16u, (fv.y1 - fv.y0 + 15u) / 16u, 1u); }
 
 hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const StageLaunch& L,
-                        hipStream_t tail, hipEvent_t ev, bool* tail_used) {
-    if (tail_used) *tail_used = false;
+                        hipStream_t tail, hipEvent_t ev, bool* has_cont) {
+    if (has_cont) *has_cont = false;
     if (fv.y1 <= fv.y0 || fv.W == 0u) return hipSuccess;
     dim3 grid = grid_for(fv), block(kBlock);
     if (stage == 0) hipLaunchKernelGGL(gbuffer_kernel, grid, block, 0, stream, sc, fv);
@@ -362,12 +362,14 @@ hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hip
         else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv, queue(0), first);
         dim3 qgrid((L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
         hipStream_t cs = stream;
-        if (tail && ev && L.ncuts && L.cuts[0] < fv.max_depth) {
-            hipError_t e = hipEventRecord(ev, stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(tail, ev, 0);
-            if (e != hipSuccess) return e;
-            cs = tail;
-            if (tail_used) *tail_used = true;
+        if (L.ncuts && L.cuts[0] < fv.max_depth) {
+            if (has_cont) *has_cont = true;
+            if (ev) {
+                hipError_t e = hipEventRecord(ev, stream);
+                if (e == hipSuccess && tail) e = hipStreamWaitEvent(tail, ev, 0);
+                if (e != hipSuccess) return e;
+                if (tail) cs = tail;
+            }
         }
         for (uint32_t k = 0; k < L.ncuts && L.cuts[k] < fv.max_depth; ++k) {
             uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;

@@ -8,9 +8,9 @@ namespace frt {
 // buffer that is written again two launches later starts from slot 0. compaction = the opt-in workgroup-compacting kernels.
 static constexpr int kMaxCuts = 4;
 struct StageLaunch { bool compaction; uint32_t ncuts; uint32_t cuts[kMaxCuts]; uint32_t* qwords[2]; uint32_t* counts; uint32_t capacity; };
-// stage: 0 G-buffer, 1 temporal, 2 spatial + shade, 3 post. Rows [fv.y0, fv.y1). Asynchronous on `stream`. With `tail` set, the
-// continuation launches of a traced stage go to that stream instead, ordered after the pixel kernel through `ev`; *tail_used
-// tells whether anything was put there.
+// stage: 0 G-buffer, 1 temporal, 2 spatial + shade, 3 post. Rows [fv.y0, fv.y1). Asynchronous on `stream`.
+// Traced stages with a cut: `ev` (optional) is recorded on `stream` right after the pixel kernel; with `tail` set the continuation
+// launches go to that stream, ordered behind `ev`. *has_cont tells whether the stage has continuation launches at all.
 hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const StageLaunch& L,
-                        hipStream_t tail = nullptr, hipEvent_t ev = nullptr, bool* tail_used = nullptr);
+                        hipStream_t tail = nullptr, hipEvent_t ev = nullptr, bool* has_cont = nullptr);
 }

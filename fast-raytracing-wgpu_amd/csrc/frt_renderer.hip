@@ -39,7 +39,7 @@ struct frt_renderer {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side = nullptr;            // FRT_FLAG_OVERLAP_POST: the post stage runs here
-    hipEvent_t ev_spatial = nullptr, ev_post = nullptr, ev_smain = nullptr, ev_scont = nullptr;
+    hipEvent_t ev_spatial = nullptr, ev_post = nullptr, ev_smain = nullptr, ev_scont = nullptr, ev_tmain = nullptr;
     bool post_in_flight = false, scont_in_flight = false;
     uint32_t motion_slot = 0;             // which motion buffer the last G-buffer stage wrote (ping-pong under the side-stream schedule)
     uint32_t W = 0, H = 0, max_depth = 8, rb = 0, re = 0, flags = 0, motion_halo = 0;
@@ -57,6 +57,8 @@ struct frt_renderer {
     frt_stats stats{};
     struct Timed { hipEvent_t a, b; int stage; };
     std::vector<Timed> pending;
+    bool post_deferred = false;           // side-stream schedule: post(f) is launched behind the temporal pixel kernel of frame f+1
+    FrameView post_fv;                    // (or at the next sync / read), so that it fills the latency-bound temporal continuation
     void* buf(int b) const { return arena + off[b]; }
 };
 
@@ -141,7 +143,9 @@ static void fill_frame_view(const frt_renderer* r, const frt_camera_uniform* cam
     memcpy(&fv.cam, cam, sizeof(CameraView));
 }
 
+static int launch_deferred_post(frt_renderer* r);
 static int sync_all(frt_renderer* r) {
+    if (r->post_deferred) { int rc_ = launch_deferred_post(r); if (rc_) return rc_; }
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (r->side) HIP_TRY(hipStreamSynchronize(r->side));
     return FRT_OK;
@@ -314,6 +318,7 @@ void frt_renderer_destroy(frt_renderer* r) {
     if (r->ev_post) (void)hipEventDestroy(r->ev_post);
     if (r->ev_smain) (void)hipEventDestroy(r->ev_smain);
     if (r->ev_scont) (void)hipEventDestroy(r->ev_scont);
+    if (r->ev_tmain) (void)hipEventDestroy(r->ev_tmain);
     for (auto& t : r->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (void* p : r->scene_allocs) (void)hipFree(p);
     if (r->own_arena && r->arena) (void)hipFree(r->arena);
@@ -338,6 +343,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         HIP_TRY(hipEventCreateWithFlags(&r->ev_post, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&r->ev_smain, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&r->ev_scont, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_tmain, hipEventDisableTiming));
     }
     r->arena_bytes = arena_layout(r->W, r->H, r->off);
     if (o && o->device_arena) {
@@ -391,6 +397,23 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
     return r;
 }
 
+static int launch_deferred_post(frt_renderer* r) {
+    r->post_deferred = false;
+    frt_renderer::Timed t{};
+    const bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
+    if (timed) {
+        HIP_TRY(hipEventCreate(&t.a)); HIP_TRY(hipEventCreate(&t.b)); t.stage = 3;
+        HIP_TRY(hipEventRecord(t.a, r->side));
+    }
+    StageLaunch L{};
+    HIP_TRY(launch_stage(3, r->sv, r->post_fv, r->side, L));
+    if (timed) { HIP_TRY(hipEventRecord(t.b, r->side)); r->pending.push_back(t); }
+    HIP_TRY(hipEventRecord(r->ev_post, r->side));
+    r->post_in_flight = true;
+    r->stats.launches[3] += 1;
+    return FRT_OK;
+}
+
 int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, int phases) {
     if (!r || !cam) return fail(FRT_ERR_INVALID_ARG, "render: null");
     HIP_TRY(hipSetDevice(r->device));
@@ -404,13 +427,20 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
         fv.y0 = rows[2 * stage]; fv.y1 = rows[2 * stage + 1];
         fv.ray_counters = r->d_counters + 2 * stage;
         hipStream_t q = r->stream;
-        // Side-stream schedule (FRT_FLAG_OVERLAP_POST): the tail of frame f — spatial continuation, then post — runs on the side
-        // stream while the main stream already runs G-buffer(f+1) (independent of frame f) and, once the continuation is done,
-        // temporal(f+1) (reads the spatial reservoirs the continuation finishes; overlaps post(f)).
+        // Side-stream schedule (FRT_FLAG_OVERLAP_POST). The two latency-bound tails of a frame leave the GPU mostly idle, and the two
+        // stages off the temporal -> spatial -> temporal chain are put there:
+        //   main: G(f+1) | wait S-cont(f) | T-pixel(f+1) | T-cont(f+1)          | wait post(f) | S-pixel(f+1) ...
+        //   side: S-cont(f) ............. |               | post(f), deferred    |              | S-cont(f+1) ...
+        // G-buffer(f+1) depends on nothing of frame f; post(f) needs spatial(f) complete and must finish before S-pixel(f+1)
+        // overwrites the radiance. post(f) is therefore not launched when it is requested but behind the temporal pixel kernel
+        // of the next frame (or at the next sync / read / reset, whichever comes first).
+        if (r->side && (stage == 2 || stage == 3) && r->post_deferred) { int rc_ = launch_deferred_post(r); if (rc_) return rc_; }
         if (r->side && stage == 3) {   // post(f) after spatial(f): its pixel kernel (main) and its continuation (side, in order)
             HIP_TRY(hipEventRecord(r->ev_spatial, r->stream));
             HIP_TRY(hipStreamWaitEvent(r->side, r->ev_spatial, 0));
             q = r->side;
+            const bool traced_cut = r->ncuts > 0 && r->cuts[0] < r->max_depth && !(r->flags & FRT_FLAG_COMPACTION);
+            if (traced_cut) { r->post_deferred = true; r->post_fv = fv; continue; }   // no temporal continuation to hide behind otherwise
         }
         if (r->side && (stage == 1 || stage == 2) && r->scont_in_flight) {
             HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_scont, 0));
@@ -438,14 +468,22 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
             L.counts = r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1);
             L.capacity = (uint32_t)npix;
         }
-        bool on_side = false;
-        HIP_TRY(launch_stage(stage, r->sv, fv, q, L, (r->side && stage == 2) ? r->side : nullptr, r->ev_smain, &on_side));
+        bool has_cont = false;
+        const bool tail_on_side = r->side && stage == 2;
+        hipEvent_t ev = tail_on_side ? r->ev_smain : ((r->side && stage == 1 && r->post_deferred) ? r->ev_tmain : nullptr);
+        HIP_TRY(launch_stage(stage, r->sv, fv, q, L, tail_on_side ? r->side : nullptr, ev, &has_cont));
+        const bool on_side = tail_on_side && has_cont;
         if (on_side) { HIP_TRY(hipEventRecord(r->ev_scont, r->side)); r->scont_in_flight = true; }
         if (timed) { HIP_TRY(hipEventRecord(t.b, on_side ? r->side : q)); r->pending.push_back(t); }
         if (r->side && stage == 3) { HIP_TRY(hipEventRecord(r->ev_post, r->side)); r->post_in_flight = true; }
+        if (r->side && stage == 1 && r->post_deferred) {   // post(f) behind T-pixel(f+1): it runs while T-cont(f+1) leaves the GPU idle
+            if (has_cont) HIP_TRY(hipStreamWaitEvent(r->side, r->ev_tmain, 0));
+            int rc_ = launch_deferred_post(r);
+            if (rc_) return rc_;
+        }
         if (r->side && stage == 1 && r->post_in_flight) {
-            // temporal(f+1) may overlap post(f); whatever the caller enqueues next on the main stream (the halo exchange of the
-            // previous accumulation rows, then spatial) must see post(f) finished
+            // whatever the caller enqueues next on the main stream (the halo exchange of the previous accumulation rows, then
+            // spatial) must see post(f) finished
             HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0));
             r->post_in_flight = false;
         }
@@ -477,6 +515,7 @@ int frt_renderer_reset(frt_renderer* r) {
     // Stream-level only: the reference resets every frame while the camera moves (state.rs:152), this must stay asynchronous.
     if (r->side) {
         HIP_TRY(hipSetDevice(r->device));
+        if (r->post_deferred) { int rc_ = launch_deferred_post(r); if (rc_) return rc_; }
         if (r->scont_in_flight) { HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_scont, 0)); r->scont_in_flight = false; }
         if (r->post_in_flight) { HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0)); r->post_in_flight = false; }
     }
