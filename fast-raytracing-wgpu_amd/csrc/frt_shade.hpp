@@ -409,7 +409,10 @@ FRT_HD void post_pixel_t(const FrameView& fv, uint32_t px, uint32_t py, const Ta
     f3 center_color = ctr.color, center_albedo = ctr.albedo, center_normal = ctr.normal, center_pos = ctr.pos;
     f3 sum_color = splat3(0.0f);
     float sum_weight = 0.0f;
+    // fully unrolled: dx, dy become literals and the 25 spatial weights fold to constants (same IEEE operations, evaluated by the compiler)
+#pragma unroll
     for (int dy = -2; dy <= 2; dy++) {
+#pragma unroll
         for (int dx = -2; dx <= 2; dx++) {
             int nx = (int)px + dx, ny = (int)py + dy;
             if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
