@@ -271,25 +271,122 @@ __global__ void __launch_bounds__(kBlock, 4) continue_kernel(SceneView sc, Frame
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     __shared__ uint32_t s_cnt[2];
     const uint32_t n = *qin.count;
-    if (blockIdx.x * (uint32_t)kBlock >= n) return;   // uniform per workgroup: the grid is sized for the worst case
+    if (blockIdx.x * (uint32_t)kBlock >= n) return;   // uniform per workgroup
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
-    const uint32_t slot_in = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
-    LoopState s;
-    s.alive = false;
-    ReservoirView r = zero_reservoir();
-    uint32_t pix = 0u;
-    bool owned = false;
-    if (slot_in < n) {
-        cont_load(qin, slot_in, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
-        path_loop<VARIANT>(c, s, d0, d1);
-        if (!s.alive) finish_path<STAGE>(c, pix, r, s);
+    uint32_t cnt_closest = 0u, cnt_any = 0u;
+    // stride loop: one trip with the worst-case grid of launch_stage; uniform per workgroup for any grid
+    for (uint32_t base = blockIdx.x * (uint32_t)kBlock; base < n; base += gridDim.x * (uint32_t)kBlock) {
+        const uint32_t slot_in = base + threadIdx.x;
+        LoopState s;
+        s.alive = false;
+        ReservoirView r = zero_reservoir();
+        uint32_t pix = 0u;
+        bool owned = false;
+        c.n_closest = 0u; c.n_any = 0u;
+        if (slot_in < n) {
+            cont_load(qin, slot_in, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+            path_loop<VARIANT>(c, s, d0, d1);
+            if (!s.alive) finish_path<STAGE>(c, pix, r, s);
+        }
+        const uint32_t slot = wave_reserve(qout.count, s.alive);
+        if (s.alive) cont_store(qout, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+        if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
     }
-    const uint32_t slot = wave_reserve(qout.count, s.alive);
-    if (s.alive) cont_store(qout, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
-    flush_ray_counters(fv, owned ? c.n_closest : 0u, owned ? c.n_any : 0u, s_cnt);
+    flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
+}
+
+// Two-wave tail (frt_mono.hpp: walker / lighter): a workgroup of two waves finishes 64 parked paths from bounce d0 on. Wave 0
+// walks (closest-hit ray, hit shading, BSDF sample, roulette), wave 1 evaluates each level's next-event estimate (light sample,
+// shadow ray, BSDF) one level behind, so that a level costs the longer of the two instead of their sum. Hand-over through LDS:
+// job (20 words + flag) walker -> lighter, contribution (3 words) lighter -> walker; two barriers per level, outside divergent code;
+// whether to go on is decided by the walker wave (ballot) and published with the job, so both waves leave the loop together.
+static constexpr int kPairThreads = 128, kJobWords = 21;
+template <int STAGE>
+__global__ void __launch_bounds__(kPairThreads, 3) continue_pair_kernel(SceneView sc, FrameView fv, ContQueue qin, uint32_t d0) {
+    __shared__ uint32_t s_stack[kStackDepth * kPairThreads];
+    __shared__ uint32_t s_job[kJobWords * 64];
+    __shared__ float s_con[3 * 64];
+    __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_go;
+    const uint32_t n = *qin.count;
+    if (blockIdx.x * 64u >= n) return;   // uniform per workgroup
+    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool walker = threadIdx.x < 64u;
+    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kPairThreads);
+    uint32_t cnt_closest = 0u, cnt_any = 0u;
+    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {   // one trip with launch_stage's worst-case grid
+        const uint32_t slot = base + lane;
+        ReservoirView r = zero_reservoir();
+        uint32_t pix = 0u;
+        bool owned = false, done = true;
+        c.n_closest = 0u; c.n_any = 0u;
+        LoopState s0;
+        s0.pos = s0.ffnormal = s0.throughput = s0.accumulated = s0.next_dir = s0.v1_pos = splat3(0.0f);
+        s0.last_bsdf_pdf = 0.0f; s0.previous_was_diffuse = false; s0.is_glass = false; s0.alive = false;
+        if (slot < n) {
+            if (walker) { cont_load(qin, slot, pix, c.rng, owned, s0, STAGE == 2 ? &r : nullptr); done = false; }
+            else owned = (qin.words[(size_t)2 * qin.capacity + slot] & 4u) != 0u;   // the flags word: does this rank count the path's rays
+        }
+        Walker w;
+        walker_init(w, s0);
+        NeeJob job;
+        job.pos = job.ffnormal = job.wo = job.base_color = job.throughput = splat3(0.0f);
+        job.m.roughness = job.m.metallic = job.m.transmission = 0.0f; job.m.ior = 1.0f; job.rng = 0u;
+        f3 contribution = splat3(0.0f);
+        bool go_on = true;      // walker wave: does any of its paths still run? (published to the lighter with each job)
+        for (uint32_t depth = d0;; ++depth) {
+            bool issued = false;
+            if (walker) {
+                if (lane == 0u) s_go = go_on ? 1u : 0u;
+                if (!done) issued = walker_trace<VARIANT>(c, w, depth, job);
+                if (issued) {
+                    const float f[19] = {job.pos.x, job.pos.y, job.pos.z, job.ffnormal.x, job.ffnormal.y, job.ffnormal.z, job.wo.x, job.wo.y, job.wo.z,
+                                         job.base_color.x, job.base_color.y, job.base_color.z, job.throughput.x, job.throughput.y, job.throughput.z,
+                                         job.m.roughness, job.m.metallic, job.m.transmission, job.m.ior};
+#pragma unroll
+                    for (int k = 0; k < 19; ++k) s_job[k * 64 + lane] = f2u(f[k]);
+                    s_job[19 * 64 + lane] = job.rng;
+                }
+                s_job[20 * 64 + lane] = issued ? 1u : 0u;
+            }
+            __syncthreads();
+            const bool stop = s_go == 0u;   // both waves read the same word between the two barriers and leave together
+            if (walker) {
+                if (w.pending) contribution = mk3(s_con[lane], s_con[64 + lane], s_con[128 + lane]);   // the previous level's estimate
+            } else {
+                issued = s_job[20 * 64 + lane] != 0u;
+                if (issued) {
+                    float f[19];
+#pragma unroll
+                    for (int k = 0; k < 19; ++k) f[k] = u2f(s_job[k * 64 + lane]);
+                    job.pos = mk3(f[0], f[1], f[2]); job.ffnormal = mk3(f[3], f[4], f[5]); job.wo = mk3(f[6], f[7], f[8]);
+                    job.base_color = mk3(f[9], f[10], f[11]); job.throughput = mk3(f[12], f[13], f[14]);
+                    job.m.roughness = f[15]; job.m.metallic = f[16]; job.m.transmission = f[17]; job.m.ior = f[18];
+                    job.rng = s_job[19 * 64 + lane];
+                }
+            }
+            __syncthreads();
+            if (stop) break;
+            // From here to the next barrier the two waves run side by side: the walker finishes this level and traces the next
+            // one's closest-hit ray while the lighter works through this level's estimate.
+            if (walker) {
+                if (!done && walker_shade<VARIANT>(c, w, depth, contribution, issued)) { finish_path<STAGE>(c, pix, r, w.s); done = true; }
+                go_on = __ballot(!done) != 0ull;
+            } else if (issued) {
+                f3 e = lighter_estimate<VARIANT>(c, job);
+                s_con[lane] = e.x; s_con[64 + lane] = e.y; s_con[128 + lane] = e.z;
+            }
+        }
+        __syncthreads();   // the next block of slots reuses s_job / s_con / s_go
+        if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
+    }
+    flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
 }
 
 // Post / accumulate: a 5x5 bilateral + 3x3 variance stencil (post.wgsl:95-170). The 16x16 pixel workgroup first stages its
@@ -360,7 +457,9 @@ hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hip
         uint32_t first = L.ncuts ? L.cuts[0] : fv.max_depth;
         if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, block, 0, stream, sc, fv, queue(0), first);
         else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv, queue(0), first);
-        dim3 qgrid((L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
+        // worst-case grids (every pixel parked); workgroups beyond the queue's length leave at once, which costs nothing measurable
+        // (sizing the grid from the previous frame's queue length was tried: 8100 -> 1100 workgroups, same kernel time)
+        auto blocks = [&](uint32_t, uint32_t per) { return (L.capacity + per - 1u) / per; };
         hipStream_t cs = stream;
         if (L.ncuts && L.cuts[0] < fv.max_depth) {
             if (has_cont) *has_cont = true;
@@ -373,8 +472,12 @@ hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hip
         }
         for (uint32_t k = 0; k < L.ncuts && L.cuts[k] < fv.max_depth; ++k) {
             uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
-            if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, qgrid, block, 0, cs, sc, fv, queue(k), queue(k + 1), d0, d1);
-            else hipLaunchKernelGGL(continue_kernel<2>, qgrid, block, 0, cs, sc, fv, queue(k), queue(k + 1), d0, d1);
+            if (L.pair_tail && d1 == fv.max_depth) {   // last segment: two waves per path, to the end
+                dim3 pgrid(blocks(k, 64u)), pblock(kPairThreads);
+                if (stage == 1) hipLaunchKernelGGL(continue_pair_kernel<1>, pgrid, pblock, 0, cs, sc, fv, queue(k), d0);
+                else hipLaunchKernelGGL(continue_pair_kernel<2>, pgrid, pblock, 0, cs, sc, fv, queue(k), d0);
+            } else if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, dim3(blocks(k, (uint32_t)kBlock)), block, 0, cs, sc, fv, queue(k), queue(k + 1), d0, d1);
+            else hipLaunchKernelGGL(continue_kernel<2>, dim3(blocks(k, (uint32_t)kBlock)), block, 0, cs, sc, fv, queue(k), queue(k + 1), d0, d1);
         }
     }
     return hipGetLastError();

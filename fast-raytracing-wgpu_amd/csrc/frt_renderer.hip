@@ -54,6 +54,7 @@ struct frt_renderer {
     uint32_t* d_qwords = nullptr;          // continuation queues: [stage 1|2][A|B] x kContWordsSpatial x npix words
     uint32_t* d_qcount = nullptr;          // per stage, one counter per path segment (kMaxCuts + 1)
     uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box (sweep over 0 / 2 / 3 / 4 / 5 and multi-cut sets)
+    bool pair_tail = false;               // last path segment through the two-wave kernel (continue_pair_kernel)
     frt_stats stats{};
     struct Timed { hipEvent_t a, b; int stage; };
     std::vector<Timed> pending;
@@ -362,6 +363,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         // is bound by the latency of its longest path and the extra launch only adds to it (tools/strip_time.py: 0.79 vs 0.70 ms
         // for 1/8 of a 1080p frame), so thin strips run uncut.
         if ((size_t)r->W * (r->re - r->rb) < 600000u) r->ncuts = 0;
+        if (const char* e = getenv("FRT_PAIR")) r->pair_tail = atoi(e) != 0;   // experiment knob
         if (const char* e = getenv("FRT_CUTS")) {   // experiment knob: comma-separated ascending depths, "0" = never cut
             r->ncuts = 0;
             for (const char* p = e; *p && r->ncuts < (uint32_t)kMaxCuts;) {
@@ -460,6 +462,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
         }
         StageLaunch L{};
         L.compaction = (r->flags & FRT_FLAG_COMPACTION) != 0;
+        L.pair_tail = r->pair_tail;
         L.ncuts = r->ncuts;
         for (int k = 0; k < kMaxCuts; ++k) L.cuts[k] = r->cuts[k];
         if (stage == 1 || stage == 2) {

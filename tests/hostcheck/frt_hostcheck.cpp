@@ -29,7 +29,7 @@ struct HostCheck {
 // One stage through the cut / park / resume protocol of the continuation kernels, sequentially: every pixel runs head + bounces
 // [1, cut), survivors are parked in a host-side ContQueue, then each parked path is resumed for [cut, cut2) and [cut2, max).
 template <int STAGE>
-static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned long long rc[2]) {
+static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned long long rc[2], bool pair = false) {
     const uint32_t npix = h->W * h->H;
     std::vector<uint32_t> wa((size_t)kContWordsSpatial * npix), wb((size_t)kContWordsSpatial * npix);
     uint32_t ca = 0, cb = 0;
@@ -57,6 +57,26 @@ static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned lo
     }
     uint32_t d0 = cut;
     ContQueue* qin = &qa; ContQueue* qout = &qb;
+    if (pair) {   // the two-wave tail (walker + lighter, frt_mono.hpp), one path at a time: phase 1, exchange, phase 2, estimate
+        for (uint32_t slot = 0; slot < *qin->count; ++slot) {
+            PathCtx c(h->sv, fv, stack, 1u), cl(h->sv, fv, stack, 1u);
+            LoopState s; ReservoirView r = zero_reservoir(); uint32_t pix; bool owned;
+            cont_load(*qin, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+            Walker w; walker_init(w, s);
+            f3 contribution = splat3(0.0f);
+            for (uint32_t depth = d0;; ++depth) {
+                NeeJob job;
+                bool issued = walker_trace<V>(c, w, depth, job);
+                bool fin = walker_shade<V>(c, w, depth, contribution, issued);   // consumes the PREVIOUS level's estimate
+                if (issued) contribution = lighter_estimate<V>(cl, job);
+                if (fin) break;
+            }
+            rc[0] += c.n_closest; rc[1] += cl.n_any;
+            if (STAGE == 1) { PathState st; make_path_state(st, pix, w.s.accumulated, w.s.v1_pos); temporal_finalize(c, st); }
+            else spatial_tail(c, pix, r, w.s.accumulated, w.s.v1_pos);
+        }
+        return;
+    }
     while (*qin->count > 0) {
         uint32_t d1 = d0 + 2u < fv.max_depth ? d0 + 2u : fv.max_depth;
         *qout->count = 0;
@@ -107,7 +127,8 @@ void* hc_create(const frt_scene* s, uint32_t W, uint32_t H, uint32_t max_depth, 
 void hc_destroy(void* p) { delete (HostCheck*)p; }
 
 // sm == 1: drive the resumable state machine (frt_path.hpp) instead of the straight-line functions (frt_mono.hpp);
-// sm >= 2: straight-line functions cut at bounce depth `sm` with the continuation-queue protocol (run_stage_cut)
+// sm >= 2: straight-line functions cut at bounce depth `sm` with the continuation-queue protocol (run_stage_cut);
+// sm >= 100: cut at sm - 100, then the two-wave tail (walker / lighter) runs every parked path to its end
 void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     HostCheck* h = (HostCheck*)p;
     uint32_t cur = h->frame_count & 1u, prv = cur ^ 1u;
@@ -124,7 +145,8 @@ void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     for (int stage = 0; stage < 4; ++stage) {
         if (sm >= 2 && (stage == 1 || stage == 2)) {
             unsigned long long r2[2] = {0, 0};
-            if (stage == 1) run_stage_cut<1>(h, fv, (uint32_t)sm, r2); else run_stage_cut<2>(h, fv, (uint32_t)sm, r2);
+            const bool pair = sm >= 100; const uint32_t cutd = (uint32_t)(pair ? sm - 100 : sm);
+            if (stage == 1) run_stage_cut<1>(h, fv, cutd, r2, pair); else run_stage_cut<2>(h, fv, cutd, r2, pair);
             h->rays[0] += r2[0]; h->rays[1] += r2[1];
             continue;
         }

@@ -223,11 +223,15 @@ def test_post_overlap_flag_gives_identical_frames(gpu, orc):
         assert s.read_buffer(7, last)[p.row_begin:p.row_end].tobytes() == want[p.row_begin:p.row_end].tobytes()
 
 
-@pytest.mark.parametrize("cuts", ["0", "3", "2,3,5,6", "1,2,3,4", "5,7"])
+@pytest.mark.parametrize("cuts", ["0", "3", "2,3,5,6", "1,2,3,4", "5,7", "pair:3", "pair:3,4", "pair:1", "pair:2,6"])
 def test_every_cut_configuration_is_bit_identical(gpu, orc, monkeypatch, cuts):
     """The continuation-queue protocol (pixel kernel -> park after the roulette -> continue kernels, one counter per segment) must
     not depend on where or how often paths are cut. FRT_CUTS is the experiment knob frt_renderer_create reads."""
     frt = gpu
+    if cuts.startswith("pair:"):       # the last segment through the two-wave kernel (walker + lighter)
+        monkeypatch.setenv("FRT_PAIR", "1"); cuts = cuts[5:]
+    else:
+        monkeypatch.setenv("FRT_PAIR", "0")
     monkeypatch.setenv("FRT_CUTS", cuts)
     W, H, depth = 160, 96, 8
     fs = frt.scenes.create_cornell_box()
