@@ -51,7 +51,8 @@ struct frt_renderer {
     size_t arena_bytes = 0;
     size_t off[B_COUNT] = {};
     unsigned long long* d_counters = nullptr;
-    uint32_t* d_qwords = nullptr;          // continuation queues: [stage 1|2][A|B] x kContWordsSpatial x npix words
+    uint32_t* d_qwords = nullptr;          // continuation queues: [stage 1|2][A|B] x kContWordsSpatial x qcap words
+    uint32_t qcap = 0;                     // slots per queue = the pixels this renderer traces (its rows + the spatial halo)
     uint32_t* d_qcount = nullptr;          // per stage, one counter per path segment (kMaxCuts + 1)
     uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box (sweep over 0 / 2 / 3 / 4 / 5 and multi-cut sets)
     bool pair_tail = false;               // last path segment through the two-wave kernel (continue_pair_kernel)
@@ -356,8 +357,8 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     }
     HIP_TRY(hipMalloc((void**)&r->d_counters, 9 * sizeof(unsigned long long)));   // 4 stages x {closest, any} + halo overflow
     {   // continuation queues (worst case: every pixel parks) and the bounce depths at which paths are cut
-        size_t npix = (size_t)r->W * r->H;
-        HIP_TRY(hipMalloc((void**)&r->d_qwords, 4 * (size_t)kContWordsSpatial * npix * sizeof(uint32_t)));
+        r->qcap = r->W * std::min(r->H, (r->re - r->rb) + 2u * kHaloSpatial);   // worst case: every traced pixel parks
+        HIP_TRY(hipMalloc((void**)&r->d_qwords, 4 * (size_t)kContWordsSpatial * r->qcap * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&r->d_qcount, 2 * (kMaxCuts + 1) * sizeof(uint32_t)));
         // Parking pays when the launch saturates the chip (>= ~0.6 M pixels: +6 % at 1080p, +5 % at half a frame); a thin strip
         // is bound by the latency of its longest path and the extra launch only adds to it (tools/strip_time.py: 0.79 vs 0.70 ms
@@ -466,10 +467,10 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
         L.ncuts = r->ncuts;
         for (int k = 0; k < kMaxCuts; ++k) L.cuts[k] = r->cuts[k];
         if (stage == 1 || stage == 2) {
-            size_t npix = (size_t)r->W * r->H, qsz = (size_t)kContWordsSpatial * npix;
+            size_t qsz = (size_t)kContWordsSpatial * r->qcap;
             for (int k = 0; k < 2; ++k) L.qwords[k] = r->d_qwords + (size_t)(2 * (stage - 1) + k) * qsz;
             L.counts = r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1);
-            L.capacity = (uint32_t)npix;
+            L.capacity = r->qcap;
         }
         bool has_cont = false;
         const bool tail_on_side = r->side && stage == 2;

@@ -299,3 +299,27 @@ def test_reset_every_frame_like_a_moving_reference_camera(gpu, orc, flags):
         r.render(cam); ro.render(cam)
         compare_all(r.read_buffer, ro.read, f, f"reset sequence, flags {flags}")
         assert r.frame_count == ro.frame_count
+
+
+def test_config2_4k_eight_strips_equal_whole(gpu):
+    """BASELINE.json configs[2]: 3840x2160 cut into 8 strips of 270 rows (here on one GPU, rows exchanged through the host). Strips
+    reproduce the whole-frame renderer bit for bit; the thin strips run uncut, the whole frame cut + side-stream schedule."""
+    frt = gpu
+    from frt.dist import StripPlan, exchange_halos_host
+    W, H, N = 3840, 2160, 3
+    fs = frt.scenes.create_cornell_box()
+    cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(N)]
+    whole = frt.Renderer(fs, W, H, flags=frt.FLAG_OVERLAP_POST)
+    for c in cams: whole.render(c)
+    want = whole.read_accum(); total = whole.stats()["rays_closest"] + whole.stats()["rays_any"]
+    del whole
+    plans = [StripPlan(H, 8, k) for k in range(8)]
+    assert all(p.row_end - p.row_begin == 270 for p in plans)
+    strips = [frt.Renderer(fs, W, H, rows=(p.row_begin, p.row_end)) for p in plans]
+    for f, cam in enumerate(cams):
+        for s in strips: s.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
+        exchange_halos_host(strips, plans, f)
+        for s in strips: s.render_phases(cam, frt.PHASE_SPATIAL | frt.PHASE_POST); s.end_frame()
+    for s, p in zip(strips, plans):
+        assert np.array_equal(s.read_rows(frt.BUF_ACCUM, (N - 1) % 2, p.row_begin, p.row_end).view(np.float32).reshape(-1, W, 4), want[p.row_begin:p.row_end])
+    assert sum(s.stats()["rays_closest"] + s.stats()["rays_any"] for s in strips) == total
