@@ -6,7 +6,7 @@
 //   image 0.25.9 PNG decode; DynamicImage::resize_exact(.., Lanczos3) = vertical then horizontal pass in f32
 //                baseline JPEG decode (the crate's decoder, zune-jpeg, differs from any other decoder by +-1 in places: the
 //                IDCT and the chroma upsampling are not bit-specified by the standard)
-// Progressive JPEGs, grey / 16-bit / interlaced PNGs are not decoded: such an image becomes the white 1024 x 1024 texture the
+// Arithmetic-coded JPEGs, grey / 16-bit / interlaced PNGs are not decoded: such an image becomes the white 1024 x 1024 texture the
 // reference substitutes for formats it does not handle (loader.rs:35-44), with a warning.
 #include "frt_loader.hpp"
 #include <zlib.h>
@@ -252,11 +252,11 @@ bool decode_png(const uint8_t* d, size_t n, std::vector<uint8_t>& px, uint32_t& 
     return true;
 }
 
-// ================================================================================================ JPEG (baseline)
+// ================================================================================================ JPEG (baseline + progressive Huffman)
 // Sequential Huffman JPEG, 8-bit, three components (what gltf's importer hands the reference as R8G8B8): ITU-T T.81 decoding,
 // float separable IDCT, libjpeg-style triangle ("fancy") chroma upsampling for 2x1 / 2x2 subsampling, JFIF YCbCr -> RGB.
-// Progressive / arithmetic / 12-bit / lossless files and 1- or 4-component images are reported as unsupported (the caller falls
-// back to the white texture); single-component (grey) JPEGs are exactly the case the reference itself rejects (Format::R8).
+// Progressive Huffman files (spectral selection + successive approximation) are decoded too. Arithmetic / 12-bit / lossless files
+// and 1- or 4-component images are reported as unsupported (the caller falls back to the white texture); single-component (grey) JPEGs are exactly the case the reference itself rejects (Format::R8).
 namespace {
 struct JHuff {
     uint8_t vals[256]; int maxcode[18], valptr[17], mincode[17]; bool present = false;
@@ -314,7 +314,7 @@ int jdecode(JBits& b, const JHuff& h) {
 int jextend(int v, int t) { return (t && v < (1 << (t - 1))) ? v - (1 << t) + 1 : v; }
 const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                              35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-struct JComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; int bw = 0, bh = 0; std::vector<uint8_t> plane; };
+struct JComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; int bw = 0, bh = 0; std::vector<uint8_t> plane; std::vector<int16_t> coef; };   // coef: progressive only
 
 void jidct(const float in[64], uint8_t* out, size_t pitch) {
     static float c[8][8]; static bool init = false;
@@ -369,7 +369,7 @@ bool decode_jpeg(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, uint32_t
     JHuff hdc[4], hac[4];
     std::vector<JComp> comps;
     int hmax = 1, vmax = 1, restart = 0, mcus_x = 0, mcus_y = 0;
-    bool have_sof = false, adobe = false; int adobe_transform = -1;
+    bool have_sof = false, adobe = false, progressive = false; int adobe_transform = -1;
     size_t pos = 2;
     bool decoded_any = false;
     while (pos + 4 <= n) {
@@ -400,7 +400,8 @@ bool decode_jpeg(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, uint32_t
                 if (!(tc ? hac[th] : hdc[th]).build(s + k, s + k + 16, total)) { why = "bad DHT"; return false; }
                 k += 16 + (size_t)total;
             }
-        } else if (m == 0xC0 || m == 0xC1) {                              // SOF0 / SOF1: sequential Huffman
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {                 // SOF0 / SOF1: sequential Huffman; SOF2: progressive Huffman
+            progressive = m == 0xC2;
             if (sl < 6 || s[0] != 8) { why = "JPEG precision other than 8 bits"; return false; }
             H = ((uint32_t)s[1] << 8) | s[2]; W = ((uint32_t)s[3] << 8) | s[4];
             int nf = s[5];
@@ -416,10 +417,11 @@ bool decode_jpeg(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, uint32_t
             for (JComp& c : comps) {
                 if (hmax % c.h || vmax % c.v) { why = "fractional JPEG sampling ratio"; return false; }
                 c.bw = mcus_x * c.h; c.bh = mcus_y * c.v; c.plane.assign((size_t)c.bw * 8 * (size_t)c.bh * 8, 128);
+                if (progressive) c.coef.assign((size_t)c.bw * (size_t)c.bh * 64, 0);
             }
             have_sof = true;
-        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-            why = m == 0xC2 ? "progressive JPEG (not decoded in this build)" : "JPEG process other than baseline (not decoded in this build)"; return false;
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            why = "JPEG process other than baseline / progressive Huffman (not decoded in this build)"; return false;
         } else if (m == 0xDD) { if (sl >= 2) restart = (s[0] << 8) | s[1]; }
         else if (m == 0xEE && sl >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
         else if (m == 0xDA) {                                             // SOS + entropy-coded data
@@ -432,10 +434,77 @@ bool decode_jpeg(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, uint32_t
                 for (JComp& k : comps) if (k.id == s[1 + 2 * i]) c = &k;
                 if (!c) { why = "JPEG scan names an unknown component"; return false; }
                 c->td = s[2 + 2 * i] >> 4; c->ta = s[2 + 2 * i] & 15;
-                if (c->td > 3 || c->ta > 3 || !hdc[c->td].present || !hac[c->ta].present || !have_qt[c->tq]) { why = "JPEG scan uses a missing table"; return false; }
+                if (c->td > 3 || c->ta > 3 || !have_qt[c->tq]) { why = "JPEG scan uses a missing table"; return false; }
                 c->pred = 0; sc.push_back(c);
             }
+            const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+            if (progressive) {
+                if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1)) { why = "bad progressive scan parameters"; return false; }
+            }
+            for (JComp* c : sc) {
+                const bool need_dc = !progressive || (Ss == 0 && Ah == 0), need_ac = !progressive || Ss > 0;
+                if ((need_dc && !hdc[c->td].present) || (need_ac && !hac[c->ta].present)) { why = "JPEG scan uses a missing table"; return false; }
+            }
             JBits b; b.p = d + pos + len; b.e = d + n;
+            int eobrun = 0;
+            // one block of a progressive scan (ITU-T T.81 G.1.2; the refinement pass as in libjpeg's jdphuff.c)
+            auto pblock = [&](JComp& c, int bx, int by) -> bool {
+                int16_t* co = &c.coef[((size_t)by * (size_t)c.bw + (size_t)bx) * 64];
+                if (Ss == 0) {
+                    if (Ah == 0) {
+                        int t = jdecode(b, hdc[c.td]);
+                        if (t < 0 || t > 11) return false;
+                        c.pred += jextend(b.get(t), t);
+                        co[0] = (int16_t)(c.pred * (1 << Al));
+                    } else if (b.get(1)) co[0] = (int16_t)(co[0] | (1 << Al));
+                    return true;
+                }
+                if (Ah == 0) {
+                    if (eobrun > 0) { --eobrun; return true; }
+                    for (int k = Ss; k <= Se;) {
+                        int rs = jdecode(b, hac[c.ta]);
+                        if (rs < 0) return false;
+                        int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += b.get(r); break; }
+                            k += 16;
+                        } else {
+                            k += r;
+                            if (k > Se) return false;
+                            co[kZigzag[k]] = (int16_t)(jextend(b.get(sz), sz) * (1 << Al));
+                            ++k;
+                        }
+                    }
+                    return true;
+                }
+                const int p1 = 1 << Al, m1 = -(1 << Al);
+                int k = Ss;
+                if (eobrun == 0) {
+                    for (; k <= Se; ++k) {
+                        int rs = jdecode(b, hac[c.ta]);
+                        if (rs < 0) return false;
+                        int r = rs >> 4, sz = rs & 15, val = 0;
+                        if (sz == 0) {
+                            if (r < 15) { eobrun = 1 << r; if (r) eobrun += b.get(r); break; }
+                        } else val = b.get(1) ? p1 : m1;     // sz must be 1 here
+                        while (k <= Se) {
+                            int16_t& cv = co[kZigzag[k]];
+                            if (cv != 0) { if (b.get(1) && (cv & p1) == 0) cv = (int16_t)(cv + (cv >= 0 ? p1 : m1)); }
+                            else if (--r < 0) break;
+                            ++k;
+                        }
+                        if (val && k <= Se) co[kZigzag[k]] = (int16_t)val;
+                    }
+                }
+                if (eobrun > 0) {
+                    for (; k <= Se; ++k) {
+                        int16_t& cv = co[kZigzag[k]];
+                        if (cv != 0 && b.get(1) && (cv & p1) == 0) cv = (int16_t)(cv + (cv >= 0 ? p1 : m1));
+                    }
+                    --eobrun;
+                }
+                return true;
+            };
             auto block = [&](JComp& c, int bx, int by) -> bool {
                 float coef[64]; for (float& f : coef) f = 0.0f;
                 int t = jdecode(b, hdc[c.td]);
@@ -470,11 +539,13 @@ bool decode_jpeg(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, uint32_t
                     if (b.p + 1 < b.e) b.p += 2;
                     (void)rst; ++rst;
                     for (JComp* c : sc) c->pred = 0;
+                    eobrun = 0;
                     count = 0;
                 }
-                if (ns == 1) { if (!block(*sc[0], ux, uy)) { why = "corrupt JPEG entropy data"; return false; } }
+                auto one = [&](JComp& c, int bx, int by) { return progressive ? pblock(c, bx, by) : block(c, bx, by); };
+                if (ns == 1) { if (!one(*sc[0], ux, uy)) { why = "corrupt JPEG entropy data"; return false; } }
                 else for (JComp* c : sc) for (int v = 0; v < c->v; ++v) for (int h = 0; h < c->h; ++h)
-                    if (!block(*c, ux * c->h + h, uy * c->v + v)) { why = "corrupt JPEG entropy data"; return false; }
+                    if (!one(*c, ux * c->h + h, uy * c->v + v)) { why = "corrupt JPEG entropy data"; return false; }
                 ++count;
             }
             decoded_any = true;
@@ -486,6 +557,17 @@ bool decode_jpeg(const uint8_t* d, size_t n, std::vector<uint8_t>& rgb, uint32_t
         pos += len;
     }
     if (!have_sof || !decoded_any) { why = "JPEG without image data"; return false; }
+    if (progressive) {
+        for (JComp& c : comps) {
+            if (!have_qt[c.tq]) { why = "JPEG component without quantisation table"; return false; }
+            for (int by = 0; by < c.bh; ++by) for (int bx = 0; bx < c.bw; ++bx) {
+                const int16_t* co = &c.coef[((size_t)by * (size_t)c.bw + (size_t)bx) * 64];
+                float f[64];
+                for (int k = 0; k < 64; ++k) f[k] = (float)((int)co[k] * (int)qt[c.tq][k]);
+                jidct(f, &c.plane[((size_t)by * 8) * ((size_t)c.bw * 8) + (size_t)bx * 8], (size_t)c.bw * 8);
+            }
+        }
+    }
     std::vector<uint8_t> full[3];
     const int fw = mcus_x * hmax * 8;
     for (int i = 0; i < 3; ++i) jupsample(comps[(size_t)i].plane, comps[(size_t)i].bw * 8, comps[(size_t)i].bh * 8, hmax / comps[(size_t)i].h, vmax / comps[(size_t)i].v, full[i]);

@@ -26,7 +26,7 @@ void resize_lanczos3_rgba8(const uint8_t* src, uint32_t sw, uint32_t sh, uint8_t
 // PNG (8-bit RGB / RGBA / palette, non-interlaced; what gltf's importer hands the reference as R8G8B8 / R8G8B8A8). channels: 3 or 4.
 bool decode_png(const uint8_t* data, size_t size, std::vector<uint8_t>& pixels, uint32_t& w, uint32_t& h, uint32_t& channels, std::string& why);
 
-// Baseline (sequential Huffman, 8-bit, 3-component) JPEG -> RGB8
+// Huffman JPEG (baseline and progressive, 8-bit, 3-component) -> RGB8
 bool decode_jpeg(const uint8_t* data, size_t size, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h, std::string& why);
 
 // builder.rs:191-314

@@ -109,7 +109,7 @@ frt_scene* frt_scene_create_restir_scene(void);
 
 /* ---- model import: src/scene/loader.rs:9-181 load_gltf (+ a Wavefront OBJ subset, an extension) -------------------------
  * frt_model = the (geometries, materials, images, material_indices) tuple load_gltf returns: one geometry per mesh primitive,
- * images (PNG, baseline JPEG) decoded and Lanczos3-resized to 1024 x 1024 RGBA8 (progressive JPEG and non-RGB(A)8 files become the white fallback texture of
+ * images (PNG, JPEG) decoded and Lanczos3-resized to 1024 x 1024 RGBA8 (grey / 16-bit / arithmetic-coded files become the white fallback texture of
  * loader.rs:35-44; see frt_model_warning), materials built as loader.rs:58-99 does (metallic is always 1: material.rs:54-58).
  * Material texture slots hold IMAGE indices until frt_scene_add_gltf_materials remaps them to texture-array layers. */
 typedef struct frt_model frt_model;

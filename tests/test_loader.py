@@ -282,9 +282,10 @@ f -4/1 -1/2 -5/3 -8/4
         (tmp_path / "e.obj").write_text("v 0 0 0\n"); frt.loader.load_gltf(tmp_path / "e.obj")
 
 
-@pytest.mark.parametrize("subsampling,quality,extra", [(0, 92, {}), (1, 85, {}), (2, 75, {}), (2, 90, {"restart_marker_rows": 1}), (0, 95, {"optimize": True})])
+@pytest.mark.parametrize("subsampling,quality,extra", [(0, 92, {}), (1, 85, {}), (2, 75, {}), (2, 90, {"restart_marker_rows": 1}), (0, 95, {"optimize": True}),
+                                                       (0, 90, {"progressive": True}), (2, 80, {"progressive": True}), (1, 60, {"progressive": True, "restart_marker_rows": 2})])
 def test_baseline_jpeg_textures(frt, tmp_path, subsampling, quality, extra):
-    """Baseline JPEG (4:4:4, 4:2:2, 4:2:0, restart markers, optimised Huffman tables) against Pillow's libjpeg decode of the same
+    """Baseline and progressive JPEG (4:4:4, 4:2:2, 4:2:0, restart markers, optimised Huffman tables) against Pillow's libjpeg decode of the same
     bytes. The standard does not fix IDCT rounding or chroma upsampling, so decoders differ by a level here and there."""
     PIL = pytest.importorskip("PIL.Image")
     import io
@@ -308,7 +309,7 @@ def test_jpeg_variants_the_loader_does_not_decode(frt, tmp_path):
     PIL = pytest.importorskip("PIL.Image")
     import io
     img = _gltf.make_textures()[0][:64, :64, :3]
-    for name, kw, conv in (("progressive", {"progressive": True}, "RGB"), ("grey", {}, "L")):
+    for name, kw, conv in (("grey", {}, "L"), ("grey-progressive", {"progressive": True}, "L")):
         buf = io.BytesIO(); PIL.fromarray(img).convert(conv).save(buf, "JPEG", quality=90, **kw)
         m = frt.loader.load_gltf(_one_image_model(tmp_path, buf.getvalue(), name + ".glb"))
         assert (m.image(0) == 255).all() and len(m.warnings()) == 1 and "white" in m.warnings()[0], name
