@@ -56,6 +56,8 @@ struct frt_renderer {
     uint32_t* d_qcount = nullptr;          // per stage, one counter per path segment (kMaxCuts + 1)
     uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box (sweep over 0 / 2 / 3 / 4 / 5 and multi-cut sets)
     bool pair_tail = false;               // last path segment through the two-wave kernel (continue_pair_kernel)
+    uint32_t* d_tiles = nullptr;           // per traced stage: tile-row order [n] + tile-row cost [n] (frt_kernels.hip: TileOrder)
+    uint32_t ntiles[2] = {0, 0};           // n = tile rows of the stage
     frt_stats stats{};
     struct Timed { hipEvent_t a, b; int stage; };
     std::vector<Timed> pending;
@@ -327,6 +329,7 @@ void frt_renderer_destroy(frt_renderer* r) {
     if (r->d_counters) (void)hipFree(r->d_counters);
     if (r->d_qwords) (void)hipFree(r->d_qwords);
     if (r->d_qcount) (void)hipFree(r->d_qcount);
+    if (r->d_tiles) (void)hipFree(r->d_tiles);
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -365,6 +368,19 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         // for 1/8 of a 1080p frame), so thin strips run uncut.
         if ((size_t)r->W * (r->re - r->rb) < 600000u) r->ncuts = 0;
         if (const char* e = getenv("FRT_PAIR")) r->pair_tail = atoi(e) != 0;   // experiment knob
+        {   // tile-row orders of the two traced stages; frame 0 starts bottom row first (floors cost more than ceilings and skies)
+            uint32_t rows[8];
+            phase_rows(r, rows);
+            for (int k = 0; k < 2; ++k) r->ntiles[k] = (rows[2 * (k + 1) + 1] - rows[2 * (k + 1)] + 15u) / 16u;
+            if (r->ntiles[0] <= 1024u && r->ntiles[1] <= 1024u) {
+                const size_t total = 2 * ((size_t)r->ntiles[0] + r->ntiles[1]);
+                HIP_TRY(hipMalloc((void**)&r->d_tiles, total * sizeof(uint32_t)));
+                std::vector<uint32_t> init(total, 0u);
+                size_t o = 0;
+                for (int k = 0; k < 2; ++k) { for (uint32_t i = 0; i < r->ntiles[k]; ++i) init[o + i] = r->ntiles[k] - 1u - i; o += 2 * (size_t)r->ntiles[k]; }
+                HIP_TRY(hipMemcpy(r->d_tiles, init.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
+        }
         if (const char* e = getenv("FRT_CUTS")) {   // experiment knob: comma-separated ascending depths, "0" = never cut
             r->ncuts = 0;
             for (const char* p = e; *p && r->ncuts < (uint32_t)kMaxCuts;) {
@@ -471,6 +487,10 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
             for (int k = 0; k < 2; ++k) L.qwords[k] = r->d_qwords + (size_t)(2 * (stage - 1) + k) * qsz;
             L.counts = r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1);
             L.capacity = r->qcap;
+            if (r->d_tiles && !getenv("FRT_NO_TILE_ORDER")) {   // (the variable is an experiment knob)
+                uint32_t* p = r->d_tiles;
+                for (int k = 0; k < 2; ++k) { L.row_order[k] = p; L.row_cost[k] = p + r->ntiles[k]; L.nrows[k] = r->ntiles[k]; p += 2 * (size_t)r->ntiles[k]; }
+            }
         }
         bool has_cont = false;
         const bool tail_on_side = r->side && stage == 2;
