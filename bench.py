@@ -31,10 +31,10 @@ STAGES = ("gbuffer", "temporal", "spatial", "post")
 # Compulsory per-pixel stream bytes of each kernel in this design: G-buffer write 44; temporal read 44+36+32,
 # write 32; spatial read 36+32, write 32+8; post read 68, write 20.
 B_PX = {"gbuffer": 44, "temporal": 144, "spatial": 108, "post": 88}
-# HBM bytes per launch at 1920x1080 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r1_v9_pmc.txt),
+# HBM bytes per launch at 1920x1080 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r1_v10_pmc.txt),
 # (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM. Measured offline, not in this run.
-PMC_TRAFFIC_BYTES = {"gbuffer": (2 * 2251 + 89360) * 1024, "temporal": (2 * (134700 + 69150) + 110200 + 10510) * 1024,
-                     "spatial": (2 * (169000 + 29280) + 126400 + 17260) * 1024, "post": (2 * 135500 + 40500) * 1024}
+PMC_TRAFFIC_BYTES = {"gbuffer": (2 * 2251 + 89360) * 1024, "temporal": (2 * (134800 + 69040) + 110400 + 10510) * 1024,
+                     "spatial": (2 * (152900 + 29330) + 126800 + 17250) * 1024, "post": (2 * 135500 + 40500) * 1024}
 
 
 def cpu_share():
