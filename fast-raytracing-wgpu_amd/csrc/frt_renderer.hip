@@ -469,7 +469,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
             HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0));
             r->post_in_flight = false;
         }
-        if (stage == 1 || stage == 2)   // this stage's segment counters (after the waits: the previous frame's tail used them)
+        if ((stage == 1 || stage == 2) && r->ncuts > 0 && r->cuts[0] < r->max_depth)   // this stage's segment counters (after the waits: the previous frame's tail used them); an uncut stage has no queue
             HIP_TRY(hipMemsetAsync(r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1), 0, (kMaxCuts + 1) * sizeof(uint32_t), r->stream));
         frt_renderer::Timed t{};
         bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
