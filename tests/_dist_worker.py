@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--H", type=int, default=64); ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--balanced", type=int, default=0)
     ap.add_argument("--moving", type=int, default=0, help="motion halo rows K > 0: moving camera (tests/_scenes.py), two exchanges per frame")
+    ap.add_argument("--flags", type=int, default=0, help="frt.Renderer flags of the gpu mode (8 = the side-stream schedule bench.py uses)")
     a = ap.parse_args()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world))
     import torch
@@ -78,7 +79,7 @@ def main():
         arena = torch.empty(nbytes + 256, dtype=torch.uint8, device="cuda:0")
         off = (-arena.data_ptr()) % 256
         r = frt.Renderer(fs, W, H, rows=(rb, re), arena=arena.data_ptr() + off, arena_bytes=nbytes,
-                         stream=torch.cuda.current_stream().cuda_stream, motion_halo=K)
+                         stream=torch.cuda.current_stream().cuda_stream, motion_halo=K, flags=a.flags)
         acc = ArenaRows(r, arena, staging_device="cpu")
         for f in range(N):
             exchange_halos(acc, plan, f, when="pre")
@@ -93,7 +94,7 @@ def main():
     full = gather_strips(mine, plan).numpy()
     res = {"ok": True}
     if a.rank == 0:
-        ref = osc.renderer(W, H, 8, True, 4)
+        ref = osc.renderer(W, H, 8, True, 16 if W * H > 500000 else 4)
         for f in range(N):
             ref.render(cams[f])
         want = ref.read(7, (N - 1) % 2)

@@ -178,6 +178,9 @@ def test_two_rank_strips_through_torch_distributed(gpu, tmp_path):
     # moving camera: motion halo of 6 rows, two exchanges per frame
     res = run_ranks("gpu", 2, tmp_path, ("--H", "96", "--W", "160", "--frames", "5", "--moving", "6"))
     assert res["ok"] and res["rays_all_ranks"] == res["oracle_rays"], res
+    # bench.py's configuration: 1080p, side-stream schedule (half-frame strips are cut: continuation on the side stream, post deferred)
+    res = run_ranks("gpu", 2, tmp_path, ("--H", "1080", "--W", "1920", "--frames", "4", "--flags", "8"))
+    assert res["ok"] and res["rays_all_ranks"] == res["oracle_rays"], res
 
 
 def test_moving_camera_on_gpu(gpu, orc):
