@@ -159,8 +159,10 @@ typedef struct frt_render_opts {
                                  Reads that fall outside are counted in frt_stats.halo_overflow (the frame then differs from a 1-GPU frame). */
 } frt_render_opts;
 #define FRT_FLAG_TIMING 1u          /* record per-stage HIP events every frame (frt_stats.ms_*) */
-#define FRT_FLAG_OVERLAP_POST 8u    /* run the post stage of frame f on a second stream, concurrently with G-buffer + temporal of frame f+1
-                                       (post is off the T -> S -> T critical path; matters for thin strips / many GPUs) */
+#define FRT_FLAG_OVERLAP_POST 8u    /* side-stream schedule: the stages that hang off the temporal -> spatial -> temporal chain (the next frame's
+                                       G-buffer, this frame's post) run beside the latency-bound continuation launches on a second stream; post(f)
+                                       is then enqueued behind the temporal pixel kernel of frame f+1, or at the next sync / read / reset
+                                       (DESIGN.md section 6). Same pixels; reads and frt_renderer_sync see completed frames as without the flag. */
 #define FRT_FLAG_USE_STREAM 4u      /* opts->stream is authoritative even when NULL (= the legacy default stream, e.g. torch's current stream) */
 #define FRT_FLAG_COMPACTION 2u      /* temporal / spatial stages through the workgroup-compacting kernels (opt-in: measured slower than
                                        one thread per pixel on the Cornell Box, profiles/r1_v3_*; same pixels either way) */
