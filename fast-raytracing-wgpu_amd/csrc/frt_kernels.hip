@@ -31,8 +31,10 @@ __device__ __forceinline__ bool tile_pixel(const FrameView& fv, uint32_t& px, ui
 struct TileOrder { const uint32_t* row_order; uint32_t* row_cost; };
 __device__ __forceinline__ uint32_t ordered_tile_row(const TileOrder& to) { return to.row_order ? to.row_order[blockIdx.y] : blockIdx.y; }
 // One workgroup per traced stage; at most 1024 tile rows (16384 pixel rows). Clears the costs for the next frame.
-__global__ void __launch_bounds__(1024) tile_row_sort_kernel(uint32_t* cost0, uint32_t* order0, uint32_t n0, uint32_t* cost1, uint32_t* order1, uint32_t n1) {
+__global__ void __launch_bounds__(1024) tile_row_sort_kernel(uint32_t* cost0, uint32_t* order0, uint32_t n0, uint32_t* cost1, uint32_t* order1, uint32_t n1,
+                                                             uint32_t* zero_counts) {
     __shared__ unsigned long long s_half[2];
+    if (zero_counts && blockIdx.x == 0u && threadIdx.x <= (uint32_t)kMaxCuts) zero_counts[threadIdx.x] = 0u;   // the temporal stage's queue counters, for the next frame
     uint32_t* cost = blockIdx.x ? cost1 : cost0;
     uint32_t* order = blockIdx.x ? order1 : order0;
     const uint32_t n = blockIdx.x ? n1 : n0, i = threadIdx.x;
@@ -262,13 +264,15 @@ __device__ __forceinline__ void finish_path(PathCtx& c, uint32_t pix, const Rese
 }
 
 template <int STAGE>
-__global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, TileOrder to) {
+__global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, TileOrder to, uint32_t* zero_counts) {
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     __shared__ uint32_t s_cnt[2];
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    // the OTHER traced stage's queue counters are cleared here instead of by a memset of their own (frt_renderer.hip: counts_clean)
+    if (zero_counts && blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x <= (uint32_t)kMaxCuts) zero_counts[threadIdx.x] = 0u;
     uint32_t px, py;
     const uint32_t tile_row = ordered_tile_row(to);
     const bool active = tile_pixel_at(fv, blockIdx.x, tile_row, px, py);
@@ -490,10 +494,10 @@ hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hip
         auto queue = [&](uint32_t k) { ContQueue q; q.words = L.qwords[k & 1u]; q.count = L.counts + k; q.capacity = L.capacity; return q; };
         uint32_t first = L.ncuts ? L.cuts[0] : fv.max_depth;
         TileOrder to{L.row_order[stage - 1], L.row_cost[stage - 1]};
-        if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, block, 0, stream, sc, fv, queue(0), first, to);
-        else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv, queue(0), first, to);
+        if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, block, 0, stream, sc, fv, queue(0), first, to, L.zero_in_pixel);
+        else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv, queue(0), first, to, (uint32_t*)nullptr);
         if (stage == 2 && L.row_cost[0] && L.row_cost[1])   // next frame's row orders, behind this frame's spatial pixel kernel
-            hipLaunchKernelGGL(tile_row_sort_kernel, dim3(2), dim3(1024), 0, stream, L.row_cost[0], L.row_order[0], L.nrows[0], L.row_cost[1], L.row_order[1], L.nrows[1]);
+            hipLaunchKernelGGL(tile_row_sort_kernel, dim3(2), dim3(1024), 0, stream, L.row_cost[0], L.row_order[0], L.nrows[0], L.row_cost[1], L.row_order[1], L.nrows[1], L.zero_in_sort);
         // worst-case grids (every pixel parked); workgroups beyond the queue's length leave at once, which costs nothing measurable
         // (sizing the grid from the previous frame's queue length was tried: 8100 -> 1100 workgroups, same kernel time)
         auto blocks = [&](uint32_t, uint32_t per) { return (L.capacity + per - 1u) / per; };

@@ -56,6 +56,7 @@ struct frt_renderer {
     uint32_t* d_qcount = nullptr;          // per stage, one counter per path segment (kMaxCuts + 1)
     uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box (sweep over 0 / 2 / 3 / 4 / 5 and multi-cut sets)
     bool pair_tail = false;               // last path segment through the two-wave kernel (continue_pair_kernel)
+    bool counts_clean[2] = {false, false};   // stage's queue counters already cleared by a kernel of the other stage (no memset needed)
     uint32_t* d_tiles = nullptr;           // per traced stage: tile-row order [n] + tile-row cost [n] (frt_kernels.hip: TileOrder)
     uint32_t ntiles[2] = {0, 0};           // n = tile rows of the stage
     frt_stats stats{};
@@ -469,8 +470,12 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
             HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0));
             r->post_in_flight = false;
         }
-        if ((stage == 1 || stage == 2) && r->ncuts > 0 && r->cuts[0] < r->max_depth)   // this stage's segment counters (after the waits: the previous frame's tail used them); an uncut stage has no queue
-            HIP_TRY(hipMemsetAsync(r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1), 0, (kMaxCuts + 1) * sizeof(uint32_t), r->stream));
+        const bool traced_cut_stage = (stage == 1 || stage == 2) && r->ncuts > 0 && r->cuts[0] < r->max_depth && !(r->flags & FRT_FLAG_COMPACTION);
+        if (traced_cut_stage) {   // this stage's segment counters must be zero (after the waits: the previous frame's tail used them)
+            if (!r->counts_clean[stage - 1])
+                HIP_TRY(hipMemsetAsync(r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1), 0, (kMaxCuts + 1) * sizeof(uint32_t), r->stream));
+            r->counts_clean[stage - 1] = false;   // about to be used
+        }
         frt_renderer::Timed t{};
         bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
         if (timed) {
@@ -492,10 +497,18 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
                 for (int k = 0; k < 2; ++k) { L.row_order[k] = p; L.row_cost[k] = p + r->ntiles[k]; L.nrows[k] = r->ntiles[k]; p += 2 * (size_t)r->ntiles[k]; }
             }
         }
+        // Clearing the counters in passing saves the two memsets per frame (each sits between two dependent kernels): the temporal
+        // pixel kernel clears the spatial stage's counters (the main stream has waited for the previous spatial continuation by
+        // then), the row-order kernel behind the spatial pixel kernel clears the temporal stage's for the next frame.
+        const bool sort_runs = stage == 2 && traced_cut_stage && L.row_cost[0] && L.row_cost[1];
+        if (stage == 1 && traced_cut_stage) L.zero_in_pixel = r->d_qcount + (size_t)(kMaxCuts + 1);
+        if (sort_runs) L.zero_in_sort = r->d_qcount;
         bool has_cont = false;
         const bool tail_on_side = r->side && stage == 2;
         hipEvent_t ev = tail_on_side ? r->ev_smain : ((r->side && stage == 1 && r->post_deferred) ? r->ev_tmain : nullptr);
         HIP_TRY(launch_stage(stage, r->sv, fv, q, L, tail_on_side ? r->side : nullptr, ev, &has_cont));
+        if (stage == 1 && traced_cut_stage) r->counts_clean[1] = true;
+        if (sort_runs) r->counts_clean[0] = true;
         const bool on_side = tail_on_side && has_cont;
         if (on_side) { HIP_TRY(hipEventRecord(r->ev_scont, r->side)); r->scont_in_flight = true; }
         if (timed) { HIP_TRY(hipEventRecord(t.b, on_side ? r->side : q)); r->pending.push_back(t); }
