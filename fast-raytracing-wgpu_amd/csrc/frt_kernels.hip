@@ -496,8 +496,6 @@ hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hip
         TileOrder to{L.row_order[stage - 1], L.row_cost[stage - 1]};
         if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, block, 0, stream, sc, fv, queue(0), first, to, L.zero_in_pixel);
         else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv, queue(0), first, to, (uint32_t*)nullptr);
-        if (stage == 2 && L.row_cost[0] && L.row_cost[1])   // next frame's row orders, behind this frame's spatial pixel kernel
-            hipLaunchKernelGGL(tile_row_sort_kernel, dim3(2), dim3(1024), 0, stream, L.row_cost[0], L.row_order[0], L.nrows[0], L.row_cost[1], L.row_order[1], L.nrows[1], L.zero_in_sort);
         // worst-case grids (every pixel parked); workgroups beyond the queue's length leave at once, which costs nothing measurable
         // (sizing the grid from the previous frame's queue length was tried: 8100 -> 1100 workgroups, same kernel time)
         auto blocks = [&](uint32_t, uint32_t per) { return (L.capacity + per - 1u) / per; };
@@ -520,6 +518,9 @@ hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hip
             } else if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, dim3(blocks(k, (uint32_t)kBlock)), block, 0, cs, sc, fv, queue(k), queue(k + 1), d0, d1);
             else hipLaunchKernelGGL(continue_kernel<2>, dim3(blocks(k, (uint32_t)kBlock)), block, 0, cs, sc, fv, queue(k), queue(k + 1), d0, d1);
         }
+        // (on `stream`, i.e. beside a continuation that went to the tail stream: off the critical path)
+        if (stage == 2 && L.row_cost[0] && L.row_cost[1])   // next frame's row orders, behind this frame's spatial pixel kernel
+            hipLaunchKernelGGL(tile_row_sort_kernel, dim3(2), dim3(1024), 0, stream, L.row_cost[0], L.row_order[0], L.nrows[0], L.row_cost[1], L.row_order[1], L.nrows[1], L.zero_in_sort);
     }
     return hipGetLastError();
 }
