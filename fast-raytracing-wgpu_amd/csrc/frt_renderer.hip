@@ -373,7 +373,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
             uint32_t rows[8];
             phase_rows(r, rows);
             for (int k = 0; k < 2; ++k) r->ntiles[k] = (rows[2 * (k + 1) + 1] - rows[2 * (k + 1)] + 15u) / 16u;
-            if (r->ntiles[0] <= 1024u && r->ntiles[1] <= 1024u) {
+            if (r->ntiles[0] <= 1024u && r->ntiles[1] <= 1024u && !getenv("FRT_NO_TILE_ORDER")) {   // (the variable is an experiment knob: rows top to bottom)
                 const size_t total = 2 * ((size_t)r->ntiles[0] + r->ntiles[1]);
                 HIP_TRY(hipMalloc((void**)&r->d_tiles, total * sizeof(uint32_t)));
                 std::vector<uint32_t> init(total, 0u);
@@ -492,7 +492,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
             for (int k = 0; k < 2; ++k) L.qwords[k] = r->d_qwords + (size_t)(2 * (stage - 1) + k) * qsz;
             L.counts = r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1);
             L.capacity = r->qcap;
-            if (r->d_tiles && !getenv("FRT_NO_TILE_ORDER")) {   // (the variable is an experiment knob)
+            if (r->d_tiles) {
                 uint32_t* p = r->d_tiles;
                 for (int k = 0; k < 2; ++k) { L.row_order[k] = p; L.row_cost[k] = p + r->ntiles[k]; L.nrows[k] = r->ntiles[k]; p += 2 * (size_t)r->ntiles[k]; }
             }
