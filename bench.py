@@ -9,7 +9,7 @@ Metric (BASELINE.json): Mrays/s = (closest-hit + any-hit rays issued, counted on
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: one process per GPU, the frame is cut into N horizontal strips, one halo exchange per frame over RCCL (frt.dist);
+N > 1: one process per GPU, the frame is cut into N horizontal strips, two halo exchanges per frame over RCCL (frt.dist);
 total work is fixed ("strong" scaling). Rank 0 prints ONE JSON line.
 Extra objects: "roofline" (dominant kernel, HBM bound, algorithmic bytes per SURVEY.md §8d / DESIGN.md §6) and, at N = 1,
 "cpu_baseline" (the scalar C++ oracle over the same BVH on the host cores — a reported baseline, never the target).
@@ -31,10 +31,25 @@ STAGES = ("gbuffer", "temporal", "spatial", "post")
 # Compulsory per-pixel stream bytes of each kernel in this design: G-buffer write 44; temporal read 44+36+32,
 # write 32; spatial read 36+32, write 32+8; post read 68, write 20.
 B_PX = {"gbuffer": 44, "temporal": 144, "spatial": 108, "post": 88}
-# HBM bytes per launch at 1920x1080 from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r1_v10_pmc.txt),
-# (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM. Measured offline, not in this run.
-PMC_TRAFFIC_BYTES = {"gbuffer": (2 * 2251 + 89360) * 1024, "temporal": (2 * (134800 + 69040) + 110400 + 10510) * 1024,
-                     "spatial": (2 * (152900 + 29330) + 126800 + 17250) * 1024, "post": (2 * 135500 + 40500) * 1024}
+PMC_JSON = os.path.join(ROOT, "profiles", "r2_pmc.json")     # written by tools/pmc_to_json.py on the GPU box, committed
+
+
+def source_hash():
+    """sha256 over the kernel sources the PMC passes were measured on (csrc/*.hip, *.hpp): a profile of other code is stale."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "fast-raytracing-wgpu_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    """Per-kernel counters of the committed rocprofv3 --pmc passes, or None when they were measured on different kernel sources."""
+    try:
+        d = json.load(open(PMC_JSON))
+    except (OSError, ValueError):
+        return None
+    return d if d.get("source_hash") == source_hash() else None
 
 
 def cpu_share():
@@ -113,7 +128,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     comm_dev = f"cuda:{local_rank}" if a.backend == "nccl" else "cpu"
 
-    from frt.dist import StripPlan, ArenaRows, exchange_halos, balanced_boundaries
+    from frt.dist import StripPlan, ArenaRows, render_strip_frame, balanced_boundaries
     scene = frt.scenes.create_cornell_box()
     nl = scene.num_lights
     total = a.warmup + a.steps
@@ -132,20 +147,17 @@ def main():
     arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device=f"cuda:{local_rank}")
     off = (-arena.data_ptr()) % 256
     stream = torch.cuda.current_stream()
+    # Same instrumentation at every N: the two-stream schedule and the per-stage HIP events (pooled: two records per stage per frame).
     r = frt.Renderer(scene, W, H, max_depth=MAX_DEPTH, device=local_rank, stream=stream.cuda_stream,
                      rows=(plan.row_begin, plan.row_end) if world > 1 else None,
-                     arena=arena.data_ptr() + off, arena_bytes=nbytes,
-                     flags=frt.FLAG_OVERLAP_POST | (frt.FLAG_TIMING if world == 1 else 0))     # N > 1: per-stage events only after the timed region
+                     arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_PIPELINE | frt.FLAG_TIMING)
     rows = ArenaRows(r, arena, staging_device=None if a.backend == "nccl" else "cpu")
 
     def frame(f):
         if world == 1:
             r.render(cams[f])
         else:
-            r.render_phases(cams[f], frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
-            exchange_halos(rows, plan, f)
-            r.render_phases(cams[f], frt.PHASE_SPATIAL | frt.PHASE_POST)
-            r.end_frame()
+            render_strip_frame(r, rows, plan, cams[f], f, frt)
 
     for f in range(a.warmup):
         frame(f)
@@ -165,17 +177,6 @@ def main():
     s1 = r.stats()
 
     rays = (s1["rays_closest"] + s1["rays_any"]) - (s0["rays_closest"] + s0["rays_any"])
-    stage_frames = a.steps
-    if world > 1:
-        # The per-stage HIP events cost ~25 us per frame, too much for a thin strip, so at N > 1 the timed region runs without them
-        # and the stage times for the roofline block come from a short pass afterwards (same frames on every rank).
-        stage_frames = 16
-        r.set_timing(True)
-        s0 = r.stats()
-        for f in range(total, total + stage_frames):
-            frame(f)
-        torch.cuda.synchronize()
-        s1 = r.stats()
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -185,35 +186,61 @@ def main():
         rays = int(n.item())
 
     if rank == 0:
-        ms = [(b - c) / stage_frames for b, c in zip(s1["ms_stage"], s0["ms_stage"])]
-        stage_rays = [(s1["rays_stage"][i][0] + s1["rays_stage"][i][1] - s0["rays_stage"][i][0] - s0["rays_stage"][i][1]) / stage_frames for i in range(4)]
-        dom = max(range(4), key=lambda i: ms[i])
+        K = a.steps
+        ms = [(b - c) / K for b, c in zip(s1["ms_stage"], s0["ms_stage"])]
+        ms_merge = (s1["ms_merge"] - s0["ms_merge"]) / K
+        stage_rays = [(s1["rays_stage"][i][0] + s1["rays_stage"][i][1] - s0["rays_stage"][i][0] - s0["rays_stage"][i][1]) / K for i in range(4)]
         cpu, per_stage = (None, None)
         if world == 1 and a.cpu_frames > 0:
             cpu, per_stage = cpu_baseline(scene, cams, a.cpu_frames)
-        # algorithmic bytes of one launch of the dominant kernel: rays * (32 B * nodes/ray + 48 B * tris/ray) + pixels * B_px.
-        # nodes/ray and tris/ray are per-ray means on the canonical BVH2 measured by the oracle for that stage (same run at N = 1;
-        # the committed figures of DESIGN.md §6 otherwise).
+        # Algorithmic bytes: rays * (32 B * nodes/ray + 48 B * tris/ray) + pixels * B_px per stage. nodes/ray and tris/ray
+        # are per-ray means on the canonical BVH2 measured by the oracle for that stage (same run at N = 1; the committed figures of
+        # DESIGN.md §6 otherwise).
         defaults = {"gbuffer": (10.1, 1.7), "temporal": (18.8, 2.2), "spatial": (16.5, 2.1), "post": (0.0, 0.0)}
-        name = STAGES[dom]
-        if per_stage and name in per_stage:
-            npr, tpr = per_stage[name]["nodes_per_ray"], per_stage[name]["tris_per_ray"]
-        else:
-            npr, tpr = defaults[name]
         px = W * (plan.row_end - plan.row_begin)
-        algo_bytes = stage_rays[dom] * (32.0 * npr + 48.0 * tpr) + px * B_PX[name]
-        achieved = algo_bytes / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
+        stages = {}
+        for i, name in enumerate(STAGES):
+            npr, tpr = (per_stage[name]["nodes_per_ray"], per_stage[name]["tris_per_ray"]) if per_stage and name in per_stage else defaults[name]
+            algo = stage_rays[i] * (32.0 * npr + 48.0 * tpr) + px * B_PX[name]
+            stages[name] = {"event_ms": ms[i], "rays": stage_rays[i], "bytes_per_ray": 32.0 * npr + 48.0 * tpr, "algorithmic_bytes": algo,
+                            "logical_GBs_over_event_ms": algo / (ms[i] * 1e-3) / 1e9 if ms[i] > 0 else 0.0}
+        stages["temporal"]["merge_event_ms"] = ms_merge
+        # The stages of a frame are co-scheduled on two streams (G-buffer + T-trace of frame f+1 and post(f) run beside spatial(f)), so a
+        # stage's event time includes the time it shares the chip: the roofline is quoted for the frame's kernel set as a whole, over
+        # the wall time of the timed region; the per-stage event times are listed beside it. (Round 1 quoted the spatial stage alone:
+        # 7.17 GB / 1.33 ms = 0.68; its whole-frame figure was 11.9 GB / 2.356 ms = 0.63.)
+        frame_ms = elapsed / K * 1e3
+        algo_frame = sum(v["algorithmic_bytes"] for v in stages.values())
+        achieved = algo_frame / (frame_ms * 1e-3) / 1e9
+        pmc = load_pmc() if world == 1 else None
+        roof = {"bound": "hbm", "kernel": "frame = gbuffer_kernel + pixel_kernel<1> + continue_kernel<1> + merge_kernel + pixel_kernel<2> + continue_kernel<2> + post_kernel, co-scheduled on two streams",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc["hbm_bytes_per_frame"] if pmc else None, "avg_launch_ms": frame_ms, "algorithmic_bytes_per_launch": algo_frame,
+                "stages": stages,
+                "note": "logical BVH + stream bytes per SURVEY 8(d); the scene (91 KB) is L2-resident, so HBM carries only the per-pixel streams (traffic << algorithmic bytes) and the binding resource is the vector ALU / L2 latency: see hbm_actual and valu_issue"}
+        if pmc:
+            # HBM-actual: the PMC bytes over this run's frame time. VALU issue: wave-instructions of one frame (deterministic) x the calibrated
+            # SIMD cycles per wave-instruction (tools/valu_calib.hip) over the SIMD-cycles the frame lasted.
+            roof["hbm_actual"] = {"GBs": pmc["hbm_bytes_per_frame"] / (frame_ms * 1e-3) / 1e9, "frac": pmc["hbm_bytes_per_frame"] / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            simd_cycles = frame_ms * 1e-3 * pmc["shader_clock_ghz"] * 1e9 * pmc["simds"]
+            roof["valu_issue"] = {"wave_insts_per_frame": pmc["valu_insts_per_frame"], "cycles_per_wave_inst": pmc["cycles_per_valu_inst"],
+                                  "frac": pmc["valu_insts_per_frame"] * pmc["cycles_per_valu_inst"] / simd_cycles,
+                                  "lane_utilisation": pmc.get("lane_utilisation")}
+            roof["pmc_source"] = {"file": "profiles/r2_pmc.json", "source_hash": pmc["source_hash"], "git_head": pmc.get("git_head")}
+        elif world == 1:
+            roof["pmc_source"] = "profiles/r2_pmc.json is absent or was measured on other kernel sources: traffic / hbm_actual / valu_issue withheld"
+        par = "1 GPU, two-stream schedule"
+        if world > 1:
+            par = (f"{world} work-balanced image strips {bounds}; per frame 2 halo exchanges per neighbour ({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'}): "
+                   "12 reservoir rows overlapped with the spatial stage's interior rows, 1 accumulation row on the post stream")
         out = {
             "metric": "Mrays/sec, 1920x1080 8-bounce Cornell Box", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": frame_ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell Box 1920x1080, MAX_DEPTH 8, 1 candidate path/pixel/frame, 4-stage ReSTIR-PT frame (BASELINE.json configs[1])",
-                       "rays_per_frame": rays / a.steps, "parallelism": "1 GPU" if world == 1 else f"{world} work-balanced image strips {bounds}, 1 halo exchange/frame ({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'})"},
-            "roofline": {"bound": "hbm", "kernel": {0: "gbuffer_kernel", 1: "temporal stage = pixel_kernel<1> + continue_kernel<1>", 2: "spatial + shade stage = pixel_kernel<2> + continue_kernel<2>", 3: "post_kernel"}[dom], "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC_BYTES.get(name) if world == 1 else None,
-                         "avg_launch_ms": ms[dom], "launches_per_step": 2 if (dom in (1, 2) and px >= 600000) else 1, "algorithmic_bytes_per_launch": algo_bytes,
-                         "bytes_per_ray": 32.0 * npr + 48.0 * tpr, "rays_per_launch": stage_rays[dom],
-                         "note": "scene (91 KB) is L2-resident; HBM sees only the per-pixel streams, so the HBM fraction is small by construction (SURVEY F9)"},
+                       "rays_per_frame": rays / a.steps, "parallelism": par,
+                       "speculated_frames": s1["speculated_frames"] - s0["speculated_frames"], "queue_overflow": s1["queue_overflow"]},
+            "roofline": roof,
             "stage_ms": dict(zip(STAGES, ms)),
         }
         if cpu:

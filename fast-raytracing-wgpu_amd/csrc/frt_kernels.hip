@@ -23,31 +23,34 @@ __device__ __forceinline__ bool tile_pixel(const FrameView& fv, uint32_t& px, ui
 
 // Which row of 16x16 tiles a workgroup of a traced stage takes. The time a tile needs varies threefold over the image (ceiling vs
 // floor of a Cornell Box) and a launch ends when its last workgroup does, so the sweep over the tile rows starts at the expensive
-// end of the image and finishes on the cheap one: `row_order` is the identity or its reverse, chosen from the workgroup times the top and
-// the bottom eighth of the image reported in the previous frame (`row_cost`, accumulated at the end of the kernel; tile_row_sort_kernel).
-// A sweep, not a sort: orders that scatter the rows (or single tiles) by cost were measured and lose more to the broken
-// neighbourhood of consecutive workgroups (2.45 / 2.37 ms) than the shorter tail gains (2.35 ms against 2.42 top to bottom).
-// Scheduling only: which pixels a workgroup computes, never what it computes.
-struct TileOrder { const uint32_t* row_order; uint32_t* row_cost; };
-__device__ __forceinline__ uint32_t ordered_tile_row(const TileOrder& to) { return to.row_order ? to.row_order[blockIdx.y] : blockIdx.y; }
-// One workgroup per traced stage; at most 1024 tile rows (16384 pixel rows). Clears the costs for the next frame.
-__global__ void __launch_bounds__(1024) tile_row_sort_kernel(uint32_t* cost0, uint32_t* order0, uint32_t n0, uint32_t* cost1, uint32_t* order1, uint32_t n1,
-                                                             uint32_t* zero_counts) {
-    __shared__ unsigned long long s_half[2];
-    if (zero_counts && blockIdx.x == 0u && threadIdx.x <= (uint32_t)kMaxCuts) zero_counts[threadIdx.x] = 0u;   // the temporal stage's queue counters, for the next frame
-    uint32_t* cost = blockIdx.x ? cost1 : cost0;
-    uint32_t* order = blockIdx.x ? order1 : order0;
-    const uint32_t n = blockIdx.x ? n1 : n0, i = threadIdx.x;
-    if (i < 2u) s_half[i] = 0ull;
-    __syncthreads();
-    const uint32_t k = n / 8u > 0u ? n / 8u : 1u;   // the sweep should END on the cheaper eighth of the image
-    if (i < k) atomicAdd(&s_half[0], (unsigned long long)cost[i]);
-    if (i < n && i + k >= n) atomicAdd(&s_half[1], (unsigned long long)cost[i]);
-    __syncthreads();
-    if (i < n) {
-        const bool bottom_first = s_half[0] <= s_half[1];
-        order[i] = bottom_first ? n - 1u - i : i;
-        cost[i] = 0u;
+// end of the image and finishes on the cheap one: top to bottom or bottom to top, chosen from the workgroup times the top and the
+// bottom eighth of the image reported in the stage's previous launch. A sweep, not a sort: orders that scatter the rows (or single
+// tiles) by cost were measured and lose more to the broken neighbourhood of consecutive workgroups (2.45 / 2.37 ms) than the shorter
+// tail gains (2.35 ms against 2.42 top to bottom). Scheduling only: which pixels a workgroup computes, never what it computes.
+// State per traced stage (device memory, 6 words): [0] flip (1 = bottom tile row first), [1] ticket of finished workgroups,
+// [2..3] summed time of the top eighth, [4..5] of the bottom eighth. The LAST workgroup of a launch to finish (ticket) turns the two
+// sums into the next launch's direction and clears them: no extra kernel, nothing on the critical path.
+struct TileOrder { uint32_t* st; uint32_t nrows; };
+__device__ __forceinline__ uint32_t ordered_tile_row(const TileOrder& to) {
+    if (!to.st) return blockIdx.y;
+    return to.st[0] ? to.nrows - 1u - blockIdx.y : blockIdx.y;
+}
+__device__ __forceinline__ void report_tile_cost(const TileOrder& to, uint32_t tile_row, unsigned long long t_begin) {
+    if (!to.st || threadIdx.x != 0u) return;
+    const unsigned long long cost = (__builtin_amdgcn_s_memtime() - t_begin) >> 8;
+    const uint32_t k = to.nrows / 8u > 0u ? to.nrows / 8u : 1u;
+    unsigned long long* sums = reinterpret_cast<unsigned long long*>(to.st + 2);
+    // No fences (a device-scope fence invalidates the CU's vector L1, i.e. the BVH working set of the workgroups still running there:
+    // measured +12 % on the frame). All four operations are L2 atomics; the ticket add is made to depend on the values the cost adds
+    // return, so it is issued after they have been performed, and the last workgroup reads the sums with atomics again.
+    unsigned long long seen = 0ull;
+    if (tile_row < k) seen |= atomicAdd(&sums[0], cost);
+    if (tile_row + k >= to.nrows) seen |= atomicAdd(&sums[1], cost);
+    const uint32_t one = (seen == ~0ull) ? 2u : 1u;      // always 1 (the sums never reach 2^64 - 1); keeps the dependency
+    if (atomicAdd(&to.st[1], one) == gridDim.x * gridDim.y - 1u) {   // every other workgroup has read st[0] and added its cost
+        const unsigned long long top = atomicExch(&sums[0], 0ull), bottom = atomicExch(&sums[1], 0ull);
+        to.st[0] = top <= bottom ? 1u : 0u;   // the sweep should END on the cheaper eighth of the image
+        to.st[1] = 0u;
     }
 }
 
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(kBlockC) compact_kernel(SceneView sc, FrameVie
     flush_ray_counters(fv, n_closest, n_any, s_cnt);
 }
 
-// Default temporal (STAGE 1) / spatial + shade (STAGE 2) kernels: one thread per pixel runs the primary hit and the bounces
+// Default T-trace (STAGE 1) / spatial + shade (STAGE 2) kernels: one thread per pixel runs the primary hit and the bounces
 // below `cut` (frt_mono.hpp). 83 % of the rays of a Cornell frame are fired at depth <= 2, but almost every 8x8 tile has a lane
 // that survives to depth 5-7, so an uncut wave spends most of its bounce iterations with a handful of live lanes (24 % lane
 // utilisation, profiles/r1_v4_pmc.txt). Paths still alive at `cut` are therefore PARKED: a wave ballot finds them, the leader
@@ -247,6 +250,8 @@ __global__ void __launch_bounds__(kBlockC) compact_kernel(SceneView sc, FrameVie
 // loop state at slot base + rank (SoA, so the wave writes full rows), and the lane retires. continue_kernel then resumes the
 // parked paths one per lane — dense waves again — and may park its own survivors for a further launch. Pixels are unchanged:
 // a path's arithmetic and rand() sequence do not depend on the lane or launch that runs it.
+// The queue is NOT sized for the worst case (every pixel parking): a lane whose slot lies beyond the capacity keeps its path and
+// finishes it in place (second trip of the segment loop below), counted in q.overflow so that the host can grow the queue.
 __device__ __forceinline__ uint32_t wave_reserve(uint32_t* count, bool want) {
     const unsigned long long m = __ballot(want);
     if (m == 0ull) return 0u;
@@ -256,11 +261,36 @@ __device__ __forceinline__ uint32_t wave_reserve(uint32_t* count, bool want) {
     base = __shfl(base, leader, 64);
     return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+__device__ __forceinline__ void note_queue_overflow(const ContQueue& q, bool mine) {
+    const unsigned long long m = __ballot(mine);
+    if (m != 0ull && q.overflow && (int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) atomicAdd(q.overflow, (uint32_t)__popcll(m));
+}
 
 template <int STAGE>
 __device__ __forceinline__ void finish_path(PathCtx& c, uint32_t pix, const ReservoirView& r, const LoopState& s) {
-    if (STAGE == 1) { PathState st; make_path_state(st, pix, s.accumulated, s.v1_pos); temporal_finalize(c, st); }
+    if (STAGE == 1) c.fv.cand[pix] = temporal_candidate(s.accumulated, s.v1_pos);   // T-trace ends here; merge_kernel does the rest
     else spatial_tail(c, pix, r, s.accumulated, s.v1_pos);
+}
+
+// Runs bounces [d0, d1) of the lane's path and parks a survivor in `q`; when the queue is full the lane goes on to MAX_DEPTH itself.
+// On return the path is either parked (true: state stored) or finished (false: s holds the final radiance).
+template <int VARIANT>
+__device__ __forceinline__ bool run_segment_and_park(PathCtx& c, LoopState& s, uint32_t d0, uint32_t d1, const ContQueue& q, uint32_t pix, bool owned,
+                                                     const ReservoirView* r) {
+    bool run = s.alive, parked = false;
+#pragma nounroll
+    for (int trip = 0; trip < 2; ++trip) {
+        if (run) path_loop<VARIANT>(c, s, d0, d1);
+        if (trip == 1) break;
+        const uint32_t slot = wave_reserve(q.count, s.alive);
+        parked = s.alive && slot < q.capacity;
+        run = s.alive && !parked;
+        if (parked) cont_store(q, slot, pix, c.rng, owned, s, r);
+        if (__ballot(run) == 0ull) break;      // wave-uniform
+        note_queue_overflow(q, run);
+        d0 = d1; d1 = c.fv.max_depth;          // no further cut for a path that could not be parked
+    }
+    return parked;
 }
 
 template <int STAGE>
@@ -271,7 +301,7 @@ __global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameVie
     __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    // the OTHER traced stage's queue counters are cleared here instead of by a memset of their own (frt_renderer.hip: counts_clean)
+    // the queue counters this stage's NEXT launch will use (the other set of the pair) are cleared here instead of by a memset
     if (zero_counts && blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x <= (uint32_t)kMaxCuts) zero_counts[threadIdx.x] = 0u;
     uint32_t px, py;
     const uint32_t tile_row = ordered_tile_row(to);
@@ -286,21 +316,16 @@ __global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameVie
     if (active) {
         uint32_t seed = 0u;
         if (STAGE == 1) {
-            if (fv.gpos[pix].w < 0.0f) fv.res_temporal[pix] = zero_reservoir();   // restir.wgsl:805-811
-            else { seed = temporal_seed(fv, pix); traced = true; }
+            if (!(fv.gpos[pix].w < 0.0f)) { seed = temporal_seed(fv, pix); traced = true; }   // background: merge_kernel writes the zero reservoir (restir.wgsl:805-811)
         } else if (spatial_neighbors(c, pix, r)) { seed = r.y; traced = true; }
-        if (traced) {
-            path_head<VARIANT>(c, pix, seed, s);
-            if (s.alive) path_loop<VARIANT>(c, s, 1u, cut < fv.max_depth ? cut : fv.max_depth);
-            if (!s.alive) finish_path<STAGE>(c, pix, r, s);
-        }
+        if (traced) path_head<VARIANT>(c, pix, seed, s);
     }
-    const uint32_t slot = wave_reserve(q.count, s.alive);
-    if (s.alive) cont_store(q, slot, pix, c.rng, counted, s, STAGE == 2 ? &r : nullptr);
+    const bool parked = run_segment_and_park<VARIANT>(c, s, 1u, cut < fv.max_depth ? cut : fv.max_depth, q, pix, counted, STAGE == 2 ? &r : nullptr);
+    if (traced && !parked) finish_path<STAGE>(c, pix, r, s);
     flush_ray_counters(fv, counted ? c.n_closest : 0u, counted ? c.n_any : 0u, s_cnt);   // (contains a barrier: every wave is done)
-    // this tile's share of its row's cost for the next frame's sweep direction: the time the workgroup took (ray counts mislead:
+    // this tile's share of its row's cost for the next launch's sweep direction: the time the workgroup took (ray counts mislead:
     // a diffuse wall fires a shadow ray at every bounce and is still cheaper than the glass and metal below it)
-    if (to.row_cost && threadIdx.x == 0u) atomicAdd(&to.row_cost[tile_row], (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 8));
+    report_tile_cost(to, tile_row, t_begin);
 }
 
 // Resumes parked paths for bounces [d0, d1); survivors are parked again in `qout` (d1 < MAX_DEPTH) or finished here.
@@ -308,14 +333,15 @@ template <int STAGE>
 __global__ void __launch_bounds__(kBlock, 4) continue_kernel(SceneView sc, FrameView fv, ContQueue qin, ContQueue qout, uint32_t d0, uint32_t d1) {
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     __shared__ uint32_t s_cnt[2];
-    const uint32_t n = *qin.count;
+    const uint32_t filled = *qin.count;
+    const uint32_t n = filled < qin.capacity ? filled : qin.capacity;
     if (blockIdx.x * (uint32_t)kBlock >= n) return;   // uniform per workgroup
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
     PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
     uint32_t cnt_closest = 0u, cnt_any = 0u;
-    // stride loop: one trip with the worst-case grid of launch_stage; uniform per workgroup for any grid
+    // stride loop: one trip with the grid of launch_trace_continuations; uniform per workgroup for any grid
     for (uint32_t base = blockIdx.x * (uint32_t)kBlock; base < n; base += gridDim.x * (uint32_t)kBlock) {
         const uint32_t slot_in = base + threadIdx.x;
         LoopState s;
@@ -324,107 +350,27 @@ __global__ void __launch_bounds__(kBlock, 4) continue_kernel(SceneView sc, Frame
         uint32_t pix = 0u;
         bool owned = false;
         c.n_closest = 0u; c.n_any = 0u;
-        if (slot_in < n) {
-            cont_load(qin, slot_in, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
-            path_loop<VARIANT>(c, s, d0, d1);
-            if (!s.alive) finish_path<STAGE>(c, pix, r, s);
-        }
-        const uint32_t slot = wave_reserve(qout.count, s.alive);
-        if (s.alive) cont_store(qout, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+        const bool have = slot_in < n;
+        if (have) cont_load(qin, slot_in, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+        const bool parked = run_segment_and_park<VARIANT>(c, s, d0, d1, qout, pix, owned, STAGE == 2 ? &r : nullptr);
+        if (have && !parked) finish_path<STAGE>(c, pix, r, s);
         if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
     }
     flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
 }
 
-// Two-wave tail (frt_mono.hpp: walker / lighter): a workgroup of two waves finishes 64 parked paths from bounce d0 on. Wave 0
-// walks (closest-hit ray, hit shading, BSDF sample, roulette), wave 1 evaluates each level's next-event estimate (light sample,
-// shadow ray, BSDF) one level behind, so that a level costs the longer of the two instead of their sum. Hand-over through LDS:
-// job (20 words + flag) walker -> lighter, contribution (3 words) lighter -> walker; two barriers per level, outside divergent code;
-// whether to go on is decided by the walker wave (ballot) and published with the job, so both waves leave the loop together.
-static constexpr int kPairThreads = 128, kJobWords = 21;
-template <int STAGE>
-__global__ void __launch_bounds__(kPairThreads, 3) continue_pair_kernel(SceneView sc, FrameView fv, ContQueue qin, uint32_t d0) {
-    __shared__ uint32_t s_stack[kStackDepth * kPairThreads];
-    __shared__ uint32_t s_job[kJobWords * 64];
-    __shared__ float s_con[3 * 64];
-    __shared__ uint32_t s_cnt[2];
-    __shared__ uint32_t s_go;
-    const uint32_t n = *qin.count;
-    if (blockIdx.x * 64u >= n) return;   // uniform per workgroup
-    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
-    const uint32_t lane = threadIdx.x & 63u;
-    const bool walker = threadIdx.x < 64u;
-    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kPairThreads);
-    uint32_t cnt_closest = 0u, cnt_any = 0u;
-    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {   // one trip with launch_stage's worst-case grid
-        const uint32_t slot = base + lane;
-        ReservoirView r = zero_reservoir();
-        uint32_t pix = 0u;
-        bool owned = false, done = true;
-        c.n_closest = 0u; c.n_any = 0u;
-        LoopState s0;
-        s0.pos = s0.ffnormal = s0.throughput = s0.accumulated = s0.next_dir = s0.v1_pos = splat3(0.0f);
-        s0.last_bsdf_pdf = 0.0f; s0.previous_was_diffuse = false; s0.is_glass = false; s0.alive = false;
-        if (slot < n) {
-            if (walker) { cont_load(qin, slot, pix, c.rng, owned, s0, STAGE == 2 ? &r : nullptr); done = false; }
-            else owned = (qin.words[(size_t)2 * qin.capacity + slot] & 4u) != 0u;   // the flags word: does this rank count the path's rays
-        }
-        Walker w;
-        walker_init(w, s0);
-        NeeJob job;
-        job.pos = job.ffnormal = job.wo = job.base_color = job.throughput = splat3(0.0f);
-        job.m.roughness = job.m.metallic = job.m.transmission = 0.0f; job.m.ior = 1.0f; job.rng = 0u;
-        f3 contribution = splat3(0.0f);
-        bool go_on = true;      // walker wave: does any of its paths still run? (published to the lighter with each job)
-        for (uint32_t depth = d0;; ++depth) {
-            bool issued = false;
-            if (walker) {
-                if (lane == 0u) s_go = go_on ? 1u : 0u;
-                if (!done) issued = walker_trace<VARIANT>(c, w, depth, job);
-                if (issued) {
-                    const float f[19] = {job.pos.x, job.pos.y, job.pos.z, job.ffnormal.x, job.ffnormal.y, job.ffnormal.z, job.wo.x, job.wo.y, job.wo.z,
-                                         job.base_color.x, job.base_color.y, job.base_color.z, job.throughput.x, job.throughput.y, job.throughput.z,
-                                         job.m.roughness, job.m.metallic, job.m.transmission, job.m.ior};
-#pragma unroll
-                    for (int k = 0; k < 19; ++k) s_job[k * 64 + lane] = f2u(f[k]);
-                    s_job[19 * 64 + lane] = job.rng;
-                }
-                s_job[20 * 64 + lane] = issued ? 1u : 0u;
-            }
-            __syncthreads();
-            const bool stop = s_go == 0u;   // both waves read the same word between the two barriers and leave together
-            if (walker) {
-                if (w.pending) contribution = mk3(s_con[lane], s_con[64 + lane], s_con[128 + lane]);   // the previous level's estimate
-            } else {
-                issued = s_job[20 * 64 + lane] != 0u;
-                if (issued) {
-                    float f[19];
-#pragma unroll
-                    for (int k = 0; k < 19; ++k) f[k] = u2f(s_job[k * 64 + lane]);
-                    job.pos = mk3(f[0], f[1], f[2]); job.ffnormal = mk3(f[3], f[4], f[5]); job.wo = mk3(f[6], f[7], f[8]);
-                    job.base_color = mk3(f[9], f[10], f[11]); job.throughput = mk3(f[12], f[13], f[14]);
-                    job.m.roughness = f[15]; job.m.metallic = f[16]; job.m.transmission = f[17]; job.m.ior = f[18];
-                    job.rng = s_job[19 * 64 + lane];
-                }
-            }
-            __syncthreads();
-            if (stop) break;
-            // From here to the next barrier the two waves run side by side: the walker finishes this level and traces the next
-            // one's closest-hit ray while the lighter works through this level's estimate.
-            if (walker) {
-                if (!done && walker_shade<VARIANT>(c, w, depth, contribution, issued)) { finish_path<STAGE>(c, pix, r, w.s); done = true; }
-                go_on = __ballot(!done) != 0ull;
-            } else if (issued) {
-                f3 e = lighter_estimate<VARIANT>(c, job);
-                s_con[lane] = e.x; s_con[64 + lane] = e.y; s_con[128 + lane] = e.z;
-            }
-        }
-        __syncthreads();   // the next block of slots reuses s_job / s_con / s_go
-        if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
+// T-merge (frt_path.hpp: temporal_merge): RIS of the fresh candidate with the reprojected previous spatial reservoir, one thread
+// per pixel over rows [y0, y1), pixel-linear (every access is a full row segment). No rays; the only kernel of the temporal stage
+// that sits on the frame-to-frame dependency chain. Its first lanes also COMMIT the ray counts of a G-buffer + T-trace pair that
+// ran ahead of its frame (frt_renderer.hip: speculation): `pending` -> `committed`, four words.
+__global__ void __launch_bounds__(kBlock) merge_kernel(SceneView sc, FrameView fv, unsigned long long* pending, unsigned long long* committed) {
+    if (pending && blockIdx.x == 0u && threadIdx.x < 4u) {
+        const unsigned long long v = atomicExch(&pending[threadIdx.x], 0ull);
+        if (v) atomicAdd(&committed[threadIdx.x], v);
     }
-    flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
+    const size_t first = (size_t)fv.y0 * fv.W, last = (size_t)fv.y1 * fv.W;
+    const size_t pix = first + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (pix < last) temporal_merge_pixel(sc, fv, (uint32_t)pix);
 }
 
 // Post / accumulate: a 5x5 bilateral + 3x3 variance stencil (post.wgsl:95-170). The 16x16 pixel workgroup first stages its
@@ -475,52 +421,66 @@ __global__ void __launch_bounds__(kBlock) post_kernel(FrameView fv) {
     }
 }
 
-static dim3 grid_for(const FrameView& fv) { return dim3((fv.W + 15u) / 16u, (fv.y1 - fv.y0 + 15u) / 16u, 1u); }
+// jitter != 0 (PostParams.jitter): bilinear radiance / albedo taps straight from HBM (frt_shade.hpp: JitterTaps). Untuned on purpose.
+__global__ void __launch_bounds__(kBlock) post_jitter_kernel(FrameView fv) {
+    uint32_t px, py;
+    if (tile_pixel(fv, px, py)) { JitterTaps taps{fv}; post_pixel_t(fv, px, py, taps); }
+}
 
-hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const StageLaunch& L,
-                        hipStream_t tail, hipEvent_t ev, bool* has_cont) {
-    if (has_cont) *has_cont = false;
-    if (fv.y1 <= fv.y0 || fv.W == 0u) return hipSuccess;
-    dim3 grid = grid_for(fv), block(kBlock);
-    if (stage == 0) hipLaunchKernelGGL(gbuffer_kernel, grid, block, 0, stream, sc, fv);
-    else if (stage == 3) hipLaunchKernelGGL(post_kernel, grid, block, 0, stream, fv);
-    else if (stage != 1 && stage != 2) return hipErrorInvalidValue;
-    else if (L.compaction) {
-        dim3 cgrid((fv.W + 31u) / 32u, (fv.y1 - fv.y0 + 15u) / 16u, 1u), cblock(kBlockC);
-        if (stage == 1) hipLaunchKernelGGL(compact_kernel<1>, cgrid, cblock, 0, stream, sc, fv);
-        else hipLaunchKernelGGL(compact_kernel<2>, cgrid, cblock, 0, stream, sc, fv);
-    } else {
-        // pixel kernel up to the first cut, then one continuation launch per further segment
-        auto queue = [&](uint32_t k) { ContQueue q; q.words = L.qwords[k & 1u]; q.count = L.counts + k; q.capacity = L.capacity; return q; };
-        uint32_t first = L.ncuts ? L.cuts[0] : fv.max_depth;
-        TileOrder to{L.row_order[stage - 1], L.row_cost[stage - 1]};
-        if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, block, 0, stream, sc, fv, queue(0), first, to, L.zero_in_pixel);
-        else hipLaunchKernelGGL(pixel_kernel<2>, grid, block, 0, stream, sc, fv, queue(0), first, to, (uint32_t*)nullptr);
-        // worst-case grids (every pixel parked); workgroups beyond the queue's length leave at once, which costs nothing measurable
-        // (sizing the grid from the previous frame's queue length was tried: 8100 -> 1100 workgroups, same kernel time)
-        auto blocks = [&](uint32_t, uint32_t per) { return (L.capacity + per - 1u) / per; };
-        hipStream_t cs = stream;
-        if (L.ncuts && L.cuts[0] < fv.max_depth) {
-            if (has_cont) *has_cont = true;
-            if (ev) {
-                hipError_t e = hipEventRecord(ev, stream);
-                if (e == hipSuccess && tail) e = hipStreamWaitEvent(tail, ev, 0);
-                if (e != hipSuccess) return e;
-                if (tail) cs = tail;
-            }
-        }
-        for (uint32_t k = 0; k < L.ncuts && L.cuts[k] < fv.max_depth; ++k) {
-            uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
-            if (L.pair_tail && d1 == fv.max_depth) {   // last segment: two waves per path, to the end
-                dim3 pgrid(blocks(k, 64u)), pblock(kPairThreads);
-                if (stage == 1) hipLaunchKernelGGL(continue_pair_kernel<1>, pgrid, pblock, 0, cs, sc, fv, queue(k), d0);
-                else hipLaunchKernelGGL(continue_pair_kernel<2>, pgrid, pblock, 0, cs, sc, fv, queue(k), d0);
-            } else if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, dim3(blocks(k, (uint32_t)kBlock)), block, 0, cs, sc, fv, queue(k), queue(k + 1), d0, d1);
-            else hipLaunchKernelGGL(continue_kernel<2>, dim3(blocks(k, (uint32_t)kBlock)), block, 0, cs, sc, fv, queue(k), queue(k + 1), d0, d1);
-        }
-        // (on `stream`, i.e. beside a continuation that went to the tail stream: off the critical path)
-        if (stage == 2 && L.row_cost[0] && L.row_cost[1])   // next frame's row orders, behind this frame's spatial pixel kernel
-            hipLaunchKernelGGL(tile_row_sort_kernel, dim3(2), dim3(1024), 0, stream, L.row_cost[0], L.row_order[0], L.nrows[0], L.row_cost[1], L.row_order[1], L.nrows[1], L.zero_in_sort);
+static dim3 grid_for(const FrameView& fv) { return dim3((fv.W + 15u) / 16u, (fv.y1 - fv.y0 + 15u) / 16u, 1u); }
+static bool empty_rows(const FrameView& fv) { return fv.y1 <= fv.y0 || fv.W == 0u; }
+static ContQueue queue_of(const TraceLaunch& L, uint32_t k) {
+    ContQueue q; q.words = L.qwords[k & 1u]; q.count = L.counts + k; q.capacity = L.capacity; q.overflow = L.overflow; return q;
+}
+static uint32_t first_cut(const TraceLaunch& L, const FrameView& fv) { return L.ncuts ? L.cuts[0] : fv.max_depth; }
+
+hipError_t launch_gbuffer(const SceneView& sc, const FrameView& fv, hipStream_t stream) {
+    if (empty_rows(fv)) return hipSuccess;
+    hipLaunchKernelGGL(gbuffer_kernel, grid_for(fv), dim3(kBlock), 0, stream, sc, fv);
+    return hipGetLastError();
+}
+hipError_t launch_post(const FrameView& fv, hipStream_t stream) {
+    if (empty_rows(fv)) return hipSuccess;
+    if (post_is_jittered(fv)) hipLaunchKernelGGL(post_jitter_kernel, grid_for(fv), dim3(kBlock), 0, stream, fv);
+    else hipLaunchKernelGGL(post_kernel, grid_for(fv), dim3(kBlock), 0, stream, fv);
+    return hipGetLastError();
+}
+hipError_t launch_merge(const SceneView& sc, const FrameView& fv, hipStream_t stream, unsigned long long* pending, unsigned long long* committed) {
+    if (empty_rows(fv)) return hipSuccess;
+    const size_t n = (size_t)(fv.y1 - fv.y0) * fv.W;
+    hipLaunchKernelGGL(merge_kernel, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, sc, fv, pending, committed);
+    return hipGetLastError();
+}
+hipError_t launch_compact(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream) {
+    if (stage != 1 && stage != 2) return hipErrorInvalidValue;
+    if (empty_rows(fv)) return hipSuccess;
+    dim3 cgrid((fv.W + 31u) / 32u, (fv.y1 - fv.y0 + 15u) / 16u, 1u), cblock(kBlockC);
+    if (stage == 1) hipLaunchKernelGGL(compact_kernel<1>, cgrid, cblock, 0, stream, sc, fv);
+    else hipLaunchKernelGGL(compact_kernel<2>, cgrid, cblock, 0, stream, sc, fv);
+    return hipGetLastError();
+}
+// Pixel kernel of a traced stage over rows [fv.y0, fv.y1) (fv.y0 on the stage's 16-row tile grid). A stage may be launched in
+// several row ranges (a strip's interior before its halo-dependent edge rows): they share the queue; only one of them should
+// carry the tile-order state (L.tile_state) and the counter clearing (L.zero_counts).
+hipError_t launch_trace_pixels(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const TraceLaunch& L) {
+    if (stage != 1 && stage != 2) return hipErrorInvalidValue;
+    if (empty_rows(fv)) return hipSuccess;
+    const dim3 grid = grid_for(fv);
+    TileOrder to{L.tile_state, grid.y};
+    if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), to, L.zero_counts);
+    else hipLaunchKernelGGL(pixel_kernel<2>, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), to, L.zero_counts);
+    return hipGetLastError();
+}
+bool trace_has_continuations(const TraceLaunch& L, uint32_t max_depth) { return L.ncuts > 0 && L.cuts[0] < max_depth; }
+// One continuation launch per further path segment, each over min(queue length, capacity) parked paths (the grid covers the capacity;
+// workgroups beyond the queue's length leave at once).
+hipError_t launch_trace_continuations(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const TraceLaunch& L) {
+    if (stage != 1 && stage != 2) return hipErrorInvalidValue;
+    const dim3 cgrid((L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
+    for (uint32_t k = 0; k < L.ncuts && L.cuts[k] < fv.max_depth; ++k) {
+        const uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
+        if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, cgrid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1);
+        else hipLaunchKernelGGL(continue_kernel<2>, cgrid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1);
     }
     return hipGetLastError();
 }

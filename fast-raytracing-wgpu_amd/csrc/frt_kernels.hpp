@@ -3,16 +3,23 @@
 #include "frt_mono.hpp"
 
 namespace frt {
-// How to launch the traced stages: default = pixel kernel cut at cuts[0] + one continuation launch per further segment. The two
-// word buffers are used alternately; every segment has its OWN counter (counts[0 .. ncuts], zero before the stage runs), so a
-// buffer that is written again two launches later starts from slot 0. compaction = the opt-in workgroup-compacting kernels.
+// How to launch a traced stage (1 = T-trace, 2 = spatial + shade): pixel kernel cut at cuts[0] + one continuation launch per further
+// segment. The two word buffers are used alternately by the segments (the second one only exists when there are two cuts or more);
+// every segment has its OWN counter (counts[0 .. ncuts], zero before the stage runs), so a buffer that is written again two launches
+// later starts from slot 0. `zero_counts`: the counter set of this stage's NEXT launch, cleared in passing by the pixel kernel.
+// `tile_state`: the stage's sweep-direction state (frt_kernels.hip: TileOrder) or null = tile rows top to bottom.
 static constexpr int kMaxCuts = 4;
-struct StageLaunch { bool compaction; bool pair_tail; uint32_t ncuts; uint32_t cuts[kMaxCuts]; uint32_t* qwords[2]; uint32_t* counts; uint32_t capacity;
-                     uint32_t* row_order[2]; uint32_t* row_cost[2]; uint32_t nrows[2];     // per traced stage; null = tile rows top to bottom
-                     uint32_t* zero_in_pixel; uint32_t* zero_in_sort; };   // queue counters of the other stage to clear in passing (or null)
-// stage: 0 G-buffer, 1 temporal, 2 spatial + shade, 3 post. Rows [fv.y0, fv.y1). Asynchronous on `stream`.
-// Traced stages with a cut: `ev` (optional) is recorded on `stream` right after the pixel kernel; with `tail` set the continuation
-// launches go to that stream, ordered behind `ev`. *has_cont tells whether the stage has continuation launches at all.
-hipError_t launch_stage(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const StageLaunch& L,
-                        hipStream_t tail = nullptr, hipEvent_t ev = nullptr, bool* has_cont = nullptr);
+struct TraceLaunch { uint32_t ncuts; uint32_t cuts[kMaxCuts]; uint32_t* qwords[2]; uint32_t* counts; uint32_t capacity; uint32_t* overflow;
+                     uint32_t* zero_counts; uint32_t* tile_state; };
+// All launches are asynchronous on `stream` and cover rows [fv.y0, fv.y1).
+hipError_t launch_gbuffer(const SceneView& sc, const FrameView& fv, hipStream_t stream);
+hipError_t launch_trace_pixels(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const TraceLaunch& L);
+bool trace_has_continuations(const TraceLaunch& L, uint32_t max_depth);
+hipError_t launch_trace_continuations(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const TraceLaunch& L);
+// T-merge; `pending` (may be null): four ray counters {G closest, G any, T-trace closest, T-trace any} of a G-buffer + T-trace pair that
+// ran ahead of its frame, added to `committed` and cleared.
+hipError_t launch_merge(const SceneView& sc, const FrameView& fv, hipStream_t stream, unsigned long long* pending, unsigned long long* committed);
+hipError_t launch_post(const FrameView& fv, hipStream_t stream);
+// Opt-in workgroup-compacting kernels (FRT_FLAG_COMPACTION): stage 1 = the FUSED temporal stage (trace + merge), stage 2 = spatial.
+hipError_t launch_compact(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream);
 }

@@ -240,7 +240,9 @@ FRT_HD void path_loop(PathCtx& c, LoopState& s, uint32_t depth_begin, uint32_t d
 // ---- continuation records: a LoopState parked in HBM between two launches -------------------------------------------------
 // SoA over slots: word k of slot i lives at words[k * capacity + i], so a wave parking / fetching consecutive slots moves full
 // 256-byte rows per word. 22 words (88 B) per path; the spatial stage adds its merged reservoir (8 words).
-struct ContQueue { uint32_t* words; uint32_t* count; uint32_t capacity; };
+// `count` may run past `capacity`: a path that finds the queue full is finished in place by the lane that holds it (never dropped) and
+// counted in `overflow`; readers use min(*count, capacity) slots.
+struct ContQueue { uint32_t* words; uint32_t* count; uint32_t capacity; uint32_t* overflow; };
 static constexpr int kContWordsPath = 22, kContWordsSpatial = 30;
 
 FRT_HD void cont_store(const ContQueue& q, uint32_t slot, uint32_t pix, uint32_t rng, bool owned, const LoopState& s, const ReservoirView* r) {
@@ -275,151 +277,6 @@ FRT_HD void cont_load(const ContQueue& q, uint32_t slot, uint32_t& pix, uint32_t
         r->y = w[22 * cap]; r->w_sum = u2f(w[23 * cap]); r->M = w[24 * cap]; r->W = u2f(w[25 * cap]);
         r->sx = u2f(w[26 * cap]); r->sy = u2f(w[27 * cap]); r->sz = u2f(w[28 * cap]); r->p_hat = u2f(w[29 * cap]);
     }
-}
-
-// ---- two-wave tail: a "walker" and a "lighter" per path ---------------------------------------------------------------------
-// The continuation launches are bound by the latency of one bounce level, not by throughput. Within a level the
-// next-event estimate (light sample, pdf, shadow ray, BSDF) and the continuation of the path (BSDF sample, roulette, next
-// closest-hit ray) are independent once the hit is shaded, so two waves can run them side by side: the walker traces and shades
-// the hit, hands a NeeJob to the lighter, skips the random numbers the estimate will draw and walks on; the lighter returns the
-// estimate's contribution, which the walker adds at the top of the next level — before that level adds anything, i.e. in the
-// reference's order of additions (restir.wgsl:675-720). Same functions, same operands: bit-identical to path_loop.
-struct NeeJob { f3 pos, ffnormal, wo, base_color, throughput; MatParams m; uint32_t rng; };   // 20 words
-
-struct Walker {
-    LoopState s;
-    // phase 1 -> phase 2 of one level
-    Surf hit; MatParams m; f3 base_color, wo, emissive_add, light_add;
-    bool have_hit, light_hit, add_emissive, nee_issued;
-    bool pending;      // an estimate is under way whose contribution has not been added yet
-    bool ended;        // the path has terminated (it is finished once nothing is pending)
-};
-FRT_HD void walker_init(Walker& w, const LoopState& s) {
-    w.s = s; w.have_hit = false; w.light_hit = false; w.add_emissive = false; w.nee_issued = false; w.pending = false; w.ended = !s.alive;
-    w.emissive_add = splat3(0.0f); w.light_add = splat3(0.0f); w.base_color = splat3(0.0f); w.wo = splat3(0.0f);
-    w.m.roughness = 0.0f; w.m.metallic = 0.0f; w.m.transmission = 0.0f; w.m.ior = 1.0f;
-    w.hit.pos = s.pos; w.hit.ffnormal = s.ffnormal; w.hit.normal = s.ffnormal; w.hit.front_face = true;
-    w.hit.uv = mk2(0.0f, 0.0f); w.hit.t = 0.0f; w.hit.tangent = mk4(0, 0, 0, 0); w.hit.mat_id = 0u;
-}
-// Phase 1 of level `depth` (the roulette for it has been passed): closest-hit ray, geometry, material; everything of the level
-// that does not touch `accumulated`. Returns true when an estimate is wanted (job filled).
-template <int VARIANT>
-FRT_HD bool walker_trace(PathCtx& c, Walker& w, uint32_t depth, NeeJob& job) {
-    const SceneView& sc = c.sc; const FrameView& fv = c.fv;
-    w.have_hit = false; w.light_hit = false; w.add_emissive = false; w.nee_issued = false;
-    if (w.ended) return false;
-    LoopState& s = w.s;
-    f3 offset_dir = w.hit.ffnormal * signf(dot(w.hit.ffnormal, s.next_dir));
-    f3 origin = w.hit.pos + offset_dir * 0.001f;
-    HitRec h;
-    c.n_closest++;
-    trace<false>(sc, origin, s.next_dir, 0.001f, 100.0f, c.stk, c.stride, h);
-    if (h.tri == 0xFFFFFFFFu) { w.ended = true; return false; }
-    w.have_hit = true;
-    HitGeom g = fetch_hit_geometry(sc, h);
-    Surf& hit = w.hit;
-    hit.normal = g.normal_w; hit.uv = g.uv; hit.front_face = h.front;
-    hit.ffnormal = h.front ? g.normal_w : -g.normal_w;
-    hit.t = h.t; hit.pos = origin + s.next_dir * h.t; hit.mat_id = g.mat_id;
-    if (depth == 1u) s.v1_pos = hit.pos;
-    w.wo = -s.next_dir;
-    const MaterialView& mb = sc.materials[hit.mat_id];
-    w.m.roughness = mb.roughness; w.m.metallic = mb.metallic; w.m.transmission = mb.transmission; w.m.ior = mb.ior;
-    int32_t light_index_b = mb.light_index;
-    uint32_t t0i = mb.tex_info_0, t1i = mb.tex_info_1;
-    f4 tex_color = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-    uint32_t tex_id = t0i & 0xFFFFu, normal_tex_id = t0i >> 16u;
-    if (tex_id != 65535u) tex_color = sample_layer<true>(sc, tex_id, hit.uv);
-    float occlusion = 1.0f;
-    uint32_t occlusion_tex_id = t1i & 0xFFFFu, emissive_tex_id_b = t1i >> 16u;
-    if (occlusion_tex_id != 65535u) occlusion = sample_layer<false>(sc, occlusion_tex_id, hit.uv).x;
-    w.base_color = mk3(mb.base_color[0], mb.base_color[1], mb.base_color[2]) * xyz(tex_color) * occlusion;
-    if (normal_tex_id != 65535u) {
-        f3 nm = xyz(sample_layer<false>(sc, normal_tex_id, hit.uv));
-        f4 tg = hit_tangent(sc, g);
-        hit.ffnormal = perturb_normal(hit.ffnormal, xyz(tg), tg.w, nm);
-    }
-    if (light_index_b == -1 && emissive_tex_id_b != 65535u) {   // :675-678, added in phase 2
-        w.emissive_add = xyz(sample_layer<true>(sc, emissive_tex_id_b, hit.uv)) * s.throughput;
-        w.add_emissive = true;
-    }
-    if (light_index_b >= 0) {   // :683-700, added in phase 2 (the path ends there)
-        w.light_hit = true;
-        w.light_add = splat3(0.0f);
-        if (hit.front_face) {
-            const LightView& light = sc.lights[light_index_b];
-            f3 Le = mk3(light.emission[0], light.emission[1], light.emission[2]) * light.emission[3];
-            float mis_weight = 1.0f;
-            if (s.previous_was_diffuse) {
-                float dist_sq = hit.t * hit.t;
-                float light_cos = fmaxn(dot(hit.ffnormal, -w.wo), 0.0f);
-                float p_bsdf = s.last_bsdf_pdf;
-                float p_nee = (1.0f / light.area) * (dist_sq / light_cos) * (1.0f / (float)fv.cam.num_lights);
-                if (light_cos > 0.001f) mis_weight = p_bsdf / (p_bsdf + p_nee);
-                else mis_weight = 0.0f;
-            }
-            w.light_add = Le * s.throughput * mis_weight;
-        }
-        return false;
-    }
-    if (!(s.is_glass || w.m.roughness < 0.05f)) {   // :705
-        w.nee_issued = true;
-        if (fv.cam.num_lights > 0u) {
-            job.pos = hit.pos; job.ffnormal = hit.ffnormal; job.wo = w.wo; job.base_color = w.base_color; job.throughput = s.throughput;
-            job.m = w.m; job.rng = c.rng;
-            return true;
-        }
-    }
-    return false;
-}
-// The lighter's side of a level: the estimate itself, on its own random-number state and traversal stack.
-template <int VARIANT>
-FRT_HD f3 lighter_estimate(PathCtx& c, const NeeJob& job) {
-    c.rng = job.rng;
-    Surf hit;
-    hit.pos = job.pos; hit.ffnormal = job.ffnormal; hit.normal = job.ffnormal; hit.front_face = true;
-    hit.uv = mk2(0.0f, 0.0f); hit.t = 0.0f; hit.tangent = mk4(0, 0, 0, 0); hit.mat_id = 0u;
-    return nee<VARIANT>(c, hit, job.wo, job.m, job.base_color, job.throughput);
-}
-// Phase 2 of level `depth`: first the contribution of the PREVIOUS level's estimate (`contribution`, valid when w.pending), then
-// this level's own additions, the BSDF sample and the roulette of the next level. `issued` tells whether phase 1 handed out a job
-// (then the estimate's random numbers are skipped here). Returns true when the path is finished (ended, nothing pending).
-template <int VARIANT>
-FRT_HD bool walker_shade(PathCtx& c, Walker& w, uint32_t depth, f3 contribution, bool issued) {
-    const FrameView& fv = c.fv;
-    LoopState& s = w.s;
-    if (w.pending) { s.accumulated = s.accumulated + contribution; w.pending = false; }
-    if (w.ended) return true;
-    // w.have_hit is true here: a miss sets w.ended in phase 1
-    if (w.add_emissive) s.accumulated = s.accumulated + w.emissive_add;
-    if (w.light_hit) {
-        if (w.hit.front_face) s.accumulated = s.accumulated + w.light_add;
-        w.ended = true;
-        return true;
-    }
-    if (w.nee_issued) {
-        if (issued) {   // nee(): one number picks the light, sample_light draws two more (restir.wgsl:707-712, :219-222)
-            const uint32_t nl = fv.cam.num_lights;
-            uint32_t light_idx = (uint32_t)(c.rand() * (float)nl);
-            if (light_idx < nl) { c.rand(); c.rand(); }
-            w.pending = true;
-        }
-        s.previous_was_diffuse = true;
-    } else s.previous_was_diffuse = false;
-    BsdfSmp sb = sample_bsdf(c, w.wo, w.hit.ffnormal, w.hit.front_face, w.m, w.base_color);
-    if (sb.weight.x <= 0.0f && sb.weight.y <= 0.0f && sb.weight.z <= 0.0f) { w.ended = true; return !w.pending; }
-    s.last_bsdf_pdf = sb.pdf;
-    s.throughput = s.throughput * sb.weight;
-    s.next_dir = sb.wi;
-    const uint32_t next = depth + 1u;
-    if (next >= fv.max_depth) { w.ended = true; return !w.pending; }
-    if (next >= 3u) {
-        float p = fmaxn(s.throughput.x, fmaxn(s.throughput.y, s.throughput.z));
-        float survival_prob = clampf(p, 0.05f, 0.95f);
-        if (c.rand() > survival_prob) { w.ended = true; return !w.pending; }
-        s.throughput = s.throughput / survival_prob;
-    }
-    return false;
 }
 
 struct PathOut { f3 radiance; f3 v1_pos; };

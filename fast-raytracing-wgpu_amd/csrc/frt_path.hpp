@@ -238,18 +238,23 @@ FRT_HD bool temporal_begin(PathCtx& c, PathState& st, uint32_t pixel_idx) {
     path_begin(c, st, pixel_idx, temporal_seed(fv, pixel_idx));
     return true;
 }
+// The temporal stage is split at the only point where it touches the previous frame ("T-trace / T-merge"):
+//   T-trace  = trace_path of the fresh candidate (restir.wgsl:797-825): a function of this frame's G-buffer and (pixel, frame) seed only;
+//              its whole result is the candidate record (v1_pos, p_hat = luminance(radiance)), 16 bytes per pixel;
+//   T-merge  = RIS with that candidate, reprojection, merge with the previous frame's SPATIAL reservoir, store (:826-917): no rays.
+// T-trace(f+1) can therefore run while spatial(f) is still in flight; only T-merge sits on the frame-to-frame dependency chain.
+FRT_HD float4 temporal_candidate(f3 radiance, f3 v1_pos) { return make_float4(v1_pos.x, v1_pos.y, v1_pos.z, luminance(radiance)); }
+
 // RIS with the fresh candidate, temporal merge with the previous frame's spatial reservoir, store (:826-917).
-FRT_HD void temporal_finalize(PathCtx& c, const PathState& st) {
-    const SceneView& sc = c.sc; const FrameView& fv = c.fv;
-    uint32_t pixel_idx = st.pix;
+FRT_HD void temporal_merge(const SceneView& sc, const FrameView& fv, uint32_t pixel_idx, float4 cand) {
     uint32_t px = pixel_idx % fv.W, py = pixel_idx / fv.W;
     uint32_t seed_base = pixel_idx + fv.cam.frame_count * 927163u;
     uint32_t seed_candidate = pcg_hash(seed_base);
     uint32_t local_seed = seed_base;
     float4 pos_w = fv.gpos[pixel_idx];
     ReservoirView r = zero_reservoir();
-    float p_hat = luminance(st.accum);
-    update_reservoir(r, seed_candidate, p_hat, 0.5f, 1u, p_hat, st.v1_pos);
+    float p_hat = cand.w;
+    update_reservoir(r, seed_candidate, p_hat, 0.5f, 1u, p_hat, mk3(cand.x, cand.y, cand.z));
     r.W = p_hat > 0.0f ? 1.0f : 0.0f;
     float2 motion = fv.gmotion[pixel_idx];
     f2 size = mk2((float)fv.W, (float)fv.H);
@@ -295,6 +300,13 @@ FRT_HD void temporal_finalize(PathCtx& c, const PathState& st) {
     else { r.W = 0.0f; r.p_hat = 0.0f; }
     fv.res_temporal[pixel_idx] = r;
 }
+// One pixel of the T-merge pass (also the background case of restir.wgsl:805-811).
+FRT_HD void temporal_merge_pixel(const SceneView& sc, const FrameView& fv, uint32_t pixel_idx) {
+    if (fv.gpos[pixel_idx].w < 0.0f) { fv.res_temporal[pixel_idx] = zero_reservoir(); return; }
+    temporal_merge(sc, fv, pixel_idx, fv.cand[pixel_idx]);
+}
+// Fused form (the reference's order: trace, then merge, in one invocation).
+FRT_HD void temporal_finalize(PathCtx& c, const PathState& st) { temporal_merge(c.sc, c.fv, st.pix, temporal_candidate(st.accum, st.v1_pos)); }
 
 // ================================================================================================ stage 2: restir_spatial.wgsl:857-1016
 FRT_HD bool is_valid_neighbor_spatial(const SceneView& sc, f3 cp, f3 cn, uint32_t cm, f3 pp, f3 pn, uint32_t pm, f3 cam) {   // :783-814

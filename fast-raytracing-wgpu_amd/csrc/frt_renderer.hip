@@ -30,20 +30,29 @@ static_assert(sizeof(PairNode) == 64 && sizeof(TriSlot) == 48 && sizeof(ShadeTri
 // ------------------------------------------------------------------------------------------------ renderer object
 static const uint32_t kHaloGbuffer = 12;   // spatial reuse radius 10 (restir_spatial.wgsl:903, :921) + spatial halo 2
 static const uint32_t kHaloSpatial = 2;    // post reads raw radiance within +-2 rows (post.wgsl:93)
+static const uint32_t kReuseRadius = 10;   // rows of temporal reservoirs a spatial pixel may read above / below itself
 
-enum { B_GPOS0, B_GPOS1, B_GNRM0, B_GNRM1, B_GALB0, B_GALB1, B_GMOT, B_RES0, B_RES1, B_RAW, B_DISP, B_ACC0, B_ACC1, B_GMOT1, B_COUNT };
-static const uint32_t kBpp[B_COUNT] = {16, 16, 16, 16, 4, 4, 8, 32, 32, 8, 4, 16, 16, 8};
+enum { B_GPOS0, B_GPOS1, B_GNRM0, B_GNRM1, B_GALB0, B_GALB1, B_GMOT, B_RES0, B_RES1, B_RAW, B_DISP, B_ACC0, B_ACC1, B_GMOT1, B_CAND, B_COUNT };
+static const uint32_t kBpp[B_COUNT] = {16, 16, 16, 16, 4, 4, 8, 32, 32, 8, 4, 16, 16, 8, 16};
+
+// Device counters (unsigned long long each): [0..7] committed rays per stage {closest, any}; [8] halo overflow;
+// [9..12] PENDING rays of a G-buffer + T-trace pair that ran ahead of its frame (committed by its T-merge, dropped with a discarded speculation)
+enum { C_STAGE = 0, C_HALO = 8, C_PENDING = 9, C_COUNT = 13 };
+static const int kTileStateWords = 8;      // per traced stage (frt_kernels.hip: TileOrder uses 6)
 
 struct frt_renderer {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // the chain: T-merge -> spatial pixels -> spatial continuations (and everything, without FRT_FLAG_PIPELINE)
     bool own_stream = false;
-    hipStream_t side = nullptr;            // FRT_FLAG_OVERLAP_POST: the post stage runs here
-    hipEvent_t ev_spatial = nullptr, ev_post = nullptr, ev_smain = nullptr, ev_scont = nullptr, ev_tmain = nullptr;
-    bool post_in_flight = false, scont_in_flight = false;
-    uint32_t motion_slot = 0;             // which motion buffer the last G-buffer stage wrote (ping-pong under the side-stream schedule)
+    hipStream_t ahead = nullptr;           // FRT_FLAG_PIPELINE: G-buffer(f+1), T-trace(f+1)
+    hipStream_t edge = nullptr;            // FRT_FLAG_PIPELINE, strips: the spatial pixel launches of the halo-dependent edge rows (beside the interior launch)
+    bool ahead_early = false;              // start the ahead work behind T-merge (beside the spatial pixel kernel) instead of behind the spatial pixel kernel
+    hipEvent_t ev_spix = nullptr, ev_tt = nullptr, ev_tail = nullptr, ev_tm = nullptr, ev_edge = nullptr;
+    bool tail_pending = false;             // work enqueued on `ahead` that the main stream has not been ordered behind yet
+    bool edge_in_flight = false;
     uint32_t W = 0, H = 0, max_depth = 8, rb = 0, re = 0, flags = 0, motion_halo = 0;
     uint32_t frame_count = 0;
+    float jitter[2] = {0.0f, 0.0f};        // PostParams.jitter of the next post stage
     SceneView sv{};
     std::vector<void*> scene_allocs;
     uint8_t* arena = nullptr;
@@ -51,20 +60,31 @@ struct frt_renderer {
     size_t arena_bytes = 0;
     size_t off[B_COUNT] = {};
     unsigned long long* d_counters = nullptr;
-    uint32_t* d_qwords = nullptr;          // continuation queues: [stage 1|2][A|B] x kContWordsSpatial x qcap words
-    uint32_t qcap = 0;                     // slots per queue = the pixels this renderer traces (its rows + the spatial halo)
-    uint32_t* d_qcount = nullptr;          // per stage, one counter per path segment (kMaxCuts + 1)
-    uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box (sweep over 0 / 2 / 3 / 4 / 5 and multi-cut sets)
-    bool pair_tail = false;               // last path segment through the two-wave kernel (continue_pair_kernel)
-    bool counts_clean[2] = {false, false};   // stage's queue counters already cleared by a kernel of the other stage (no memset needed)
-    uint32_t* d_tiles = nullptr;           // per traced stage: tile-row order [n] + tile-row cost [n] (frt_kernels.hip: TileOrder)
-    uint32_t ntiles[2] = {0, 0};           // n = tile rows of the stage
+    // continuation queues: per traced stage one word buffer per path segment parity (the second only with two cuts or more)
+    uint32_t* d_qwords[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint32_t qcap = 0, qcap_max = 0;       // slots per queue; upper bound = every traced pixel parks
+    bool qcap_fixed = false;               // capacity given by the caller: never grown
+    uint32_t* d_qcount = nullptr;          // [stage 1|2][launch parity 0|1][kMaxCuts + 1] counters, then [stage] overflow counters
+    uint32_t qparity[2] = {0, 0};
+    uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box
+    uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state, or null
     frt_stats stats{};
-    struct Timed { hipEvent_t a, b; int stage; };
+    struct Timed { hipEvent_t a, b; int slot; };
     std::vector<Timed> pending;
-    bool post_deferred = false;           // side-stream schedule: post(f) is launched behind the temporal pixel kernel of frame f+1
-    FrameView post_fv;                    // (or at the next sync / read), so that it fills the latency-bound temporal continuation
+    std::vector<hipEvent_t> event_pool;
+    // frame in progress
+    bool frame_open = false, g_done = false, tt_done = false, tm_done = false, s_started = false, s_inner_done = false, s_edge_done = false;
+    bool from_speculation = false;
+    Timed s_timer{};
+    bool s_timed = false;
+    uint32_t motion_slot = 0;
+    // speculation: G-buffer + T-trace of the NEXT frame, enqueued on `ahead` under the camera a static scene will present
+    bool spec_valid = false, camera_static = false;
+    frt_camera_uniform spec_cam{}, last_cam{}, cur_cam{};
+    bool have_last_cam = false;
+    uint32_t spec_frame = 0, spec_motion_slot = 0;
     void* buf(int b) const { return arena + off[b]; }
+    bool pipeline() const { return ahead != nullptr; }
 };
 
 static size_t arena_layout(uint32_t W, uint32_t H, size_t off[B_COUNT]) {
@@ -126,43 +146,81 @@ static void phase_rows(const frt_renderer* r, uint32_t out[8]) {
     out[4] = lo(kHaloSpatial); out[5] = hi(kHaloSpatial);
     out[6] = r->rb; out[7] = r->re;
 }
+// Spatial rows that need nothing from a neighbour strip: [ia, ib) on the stage's 16-row tile grid (the rows whose +-10-row reuse
+// neighbourhood lies inside the strip's own temporal rows). The rest, [y0, ia) and [ib, y1), wait for the halo exchange.
+static void spatial_inner_rows(const frt_renderer* r, uint32_t y0, uint32_t y1, uint32_t& ia, uint32_t& ib) {
+    ia = y0; ib = y1;
+    if (r->rb > 0) { const uint32_t need = r->rb + kReuseRadius; ia = y0 + ((need - y0 + 15u) / 16u) * 16u; }
+    if (r->re < r->H) { const uint32_t lim = r->re > kReuseRadius ? r->re - kReuseRadius : 0u; ib = lim > y0 ? y0 + ((lim - y0) / 16u) * 16u : y0; }
+    if (ia > y1) ia = y1;
+    if (ib < ia) ib = ia;
+}
 
-static void fill_frame_view(const frt_renderer* r, const frt_camera_uniform* cam, FrameView& fv) {
-    uint32_t cur = r->frame_count & 1u, prv = cur ^ 1u;   // gbuffer.rs:299, restir.rs:543, post.rs:244
+static void fill_frame_view(const frt_renderer* r, const frt_camera_uniform* cam, uint32_t frame_count, uint32_t motion_slot, FrameView& fv) {
+    uint32_t cur = frame_count & 1u, prv = cur ^ 1u;   // gbuffer.rs:299, restir.rs:543, post.rs:244
     fv.gpos = (float4*)r->buf(B_GPOS0 + cur); fv.gnormal = (float4*)r->buf(B_GNRM0 + cur); fv.galbedo = (uint32_t*)r->buf(B_GALB0 + cur);
     fv.gpos_prev = (const float4*)r->buf(B_GPOS0 + prv); fv.gnormal_prev = (const float4*)r->buf(B_GNRM0 + prv);
     fv.galbedo_prev = (const uint32_t*)r->buf(B_GALB0 + prv);
-    fv.gmotion = (float2*)r->buf((r->side && cur) ? B_GMOT1 : B_GMOT);   // ping-pong only when post overlaps the next G-buffer
+    fv.gmotion = (float2*)r->buf(motion_slot ? B_GMOT1 : B_GMOT);   // two slots only under FRT_FLAG_PIPELINE (post(f) runs beside G-buffer(f+1))
     fv.res_temporal = (ReservoirView*)r->buf(B_RES0);   // restir.rs:362-378: reads buffers[1], writes buffers[0]
     fv.res_spatial = (ReservoirView*)r->buf(B_RES1);    // renderer.rs:292-293: spatial buffers[0] -> buffers[1]
+    fv.cand = (float4*)r->buf(B_CAND);
     fv.raw = (uint2*)r->buf(B_RAW); fv.display = (uint32_t*)r->buf(B_DISP);
     fv.history = (const float4*)r->buf(B_ACC0 + prv);   // post.rs:209-224: BG0 history = accum[1], out = accum[0]
     fv.accum = (float4*)r->buf(B_ACC0 + cur);
     fv.ray_counters = r->d_counters;
-    fv.W = r->W; fv.H = r->H; fv.frame_count = r->frame_count; fv.max_depth = r->max_depth;
+    fv.W = r->W; fv.H = r->H; fv.frame_count = frame_count; fv.max_depth = r->max_depth;
+    fv.y0 = 0; fv.y1 = 0;
     fv.own_y0 = r->rb; fv.own_y1 = r->re;
     bool whole = (r->rb == 0 && r->re == r->H);
     fv.prev_y0 = whole ? 0u : (r->rb > r->motion_halo ? r->rb - r->motion_halo : 0u);
     fv.prev_y1 = whole ? r->H : std::min(r->H, r->re + r->motion_halo);
-    fv.overflow = whole ? nullptr : r->d_counters + 8;
+    fv.overflow = whole ? nullptr : r->d_counters + C_HALO;
+    fv.jitter_x = r->jitter[0]; fv.jitter_y = r->jitter[1];
     memcpy(&fv.cam, cam, sizeof(CameraView));
 }
 
-static int launch_deferred_post(frt_renderer* r);
+// Stream-level fence: the main stream waits for everything enqueued on the `ahead` stream (no host wait).
+static int fence_ahead(frt_renderer* r) {
+    if (r->ahead && r->tail_pending) {
+        HIP_TRY(hipEventRecord(r->ev_tail, r->ahead));
+        HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_tail, 0));
+        r->tail_pending = false;
+    }
+    return FRT_OK;
+}
 static int sync_all(frt_renderer* r) {
-    if (r->post_deferred) { int rc_ = launch_deferred_post(r); if (rc_) return rc_; }
     HIP_TRY(hipStreamSynchronize(r->stream));
-    if (r->side) HIP_TRY(hipStreamSynchronize(r->side));
+    if (r->edge) HIP_TRY(hipStreamSynchronize(r->edge));
+    if (r->ahead) { HIP_TRY(hipStreamSynchronize(r->ahead)); r->tail_pending = false; }
     return FRT_OK;
 }
 
+// Per-stage timing (FRT_FLAG_TIMING): event pairs from a pool (no create / destroy per frame), resolved at the next stats call.
+static int timer_begin(frt_renderer* r, frt_renderer::Timed& t, int slot, hipStream_t q) {
+    for (hipEvent_t* e : {&t.a, &t.b}) {
+        if (r->event_pool.empty()) { HIP_TRY(hipEventCreate(e)); }
+        else { *e = r->event_pool.back(); r->event_pool.pop_back(); }
+    }
+    t.slot = slot;
+    hipError_t e_ = hipEventRecord(t.a, q);
+    if (e_ != hipSuccess) { r->event_pool.push_back(t.a); r->event_pool.push_back(t.b); return fail(FRT_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e_)); }
+    return FRT_OK;
+}
+static int timer_end(frt_renderer* r, frt_renderer::Timed& t, hipStream_t q) {
+    hipError_t e_ = hipEventRecord(t.b, q);
+    if (e_ != hipSuccess) { r->event_pool.push_back(t.a); r->event_pool.push_back(t.b); return fail(FRT_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e_)); }
+    r->pending.push_back(t);
+    return FRT_OK;
+}
 static int resolve_timing(frt_renderer* r) {
     for (auto& t : r->pending) {
         float ms = 0.0f;
         HIP_TRY(hipEventSynchronize(t.b));
         HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
-        r->stats.ms_stage[t.stage] += ms;
-        (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
+        if (t.slot < 4) r->stats.ms_stage[t.slot] += ms;
+        else r->stats.ms_merge += ms;
+        r->event_pool.push_back(t.a); r->event_pool.push_back(t.b);
     }
     r->pending.clear();
     return FRT_OK;
@@ -310,29 +368,60 @@ int frt_scene_bvh_stats(const frt_scene* s, uint32_t st[4]) {
 void frt_camera_default(float aspect, uint32_t frame_count, uint32_t num_lights, frt_camera_uniform* out) {
     camera_default(aspect, frame_count, num_lights, out);
 }
+int frt_camera_build_uniform(const float position[3], float yaw, float pitch, const float* prev_view_proj, float aspect, uint32_t frame_count,
+                             uint32_t num_lights, const float jitter[2], frt_camera_uniform* out, float* unjittered_view_proj) {
+    if (!position || !out || !(aspect > 0.0f)) return fail(FRT_ERR_INVALID_ARG, "camera_build_uniform: bad arguments");
+    camera_build_uniform(position, yaw, pitch, prev_view_proj, aspect, frame_count, num_lights, jitter ? jitter[0] : 0.0f, jitter ? jitter[1] : 0.0f, out, unjittered_view_proj);
+    return FRT_OK;
+}
+void frt_camera_halton_jitter(uint32_t index, uint32_t width, uint32_t height, float scale, float out[2]) { camera_halton_jitter(index, width, height, scale, out); }
 
 // ------------------------------------------------------------------------------------------------ renderer
 uint64_t frt_renderer_arena_bytes(uint32_t width, uint32_t height) { return arena_layout(width, height, nullptr); }
 
+static void free_queues(frt_renderer* r) {
+    for (auto& st : r->d_qwords) for (uint32_t*& p : st) { if (p) (void)hipFree(p); p = nullptr; }
+}
 void frt_renderer_destroy(frt_renderer* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
-    (void)hipStreamSynchronize(r->stream);
-    if (r->side) { (void)hipStreamSynchronize(r->side); (void)hipStreamDestroy(r->side); }
-    if (r->ev_spatial) (void)hipEventDestroy(r->ev_spatial);
-    if (r->ev_post) (void)hipEventDestroy(r->ev_post);
-    if (r->ev_smain) (void)hipEventDestroy(r->ev_smain);
-    if (r->ev_scont) (void)hipEventDestroy(r->ev_scont);
-    if (r->ev_tmain) (void)hipEventDestroy(r->ev_tmain);
+    if (r->stream || r->own_stream) (void)hipStreamSynchronize(r->stream);
+    if (r->ahead) { (void)hipStreamSynchronize(r->ahead); (void)hipStreamDestroy(r->ahead); }
+    if (r->edge) { (void)hipStreamSynchronize(r->edge); (void)hipStreamDestroy(r->edge); }
+    for (hipEvent_t e : {r->ev_spix, r->ev_tt, r->ev_tail, r->ev_tm, r->ev_edge}) if (e) (void)hipEventDestroy(e);
     for (auto& t : r->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (hipEvent_t e : r->event_pool) (void)hipEventDestroy(e);
     for (void* p : r->scene_allocs) (void)hipFree(p);
     if (r->own_arena && r->arena) (void)hipFree(r->arena);
     if (r->d_counters) (void)hipFree(r->d_counters);
-    if (r->d_qwords) (void)hipFree(r->d_qwords);
+    free_queues(r);
     if (r->d_qcount) (void)hipFree(r->d_qcount);
     if (r->d_tiles) (void)hipFree(r->d_tiles);
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
+}
+
+static const size_t kQcountWords = 2 * 2 * (kMaxCuts + 1) + 2;   // [stage][parity][segment] counters + [stage] overflow counters
+static bool stage_is_cut(const frt_renderer* r) { return r->ncuts > 0 && r->cuts[0] < r->max_depth && !(r->flags & FRT_FLAG_COMPACTION); }
+
+// Continuation queues for `cap` parked paths per segment. T-trace parks 22 words per path, spatial 30 (its merged reservoir rides along).
+static int alloc_queues(frt_renderer* r, uint32_t cap) {
+    free_queues(r);
+    r->qcap = cap;
+    if (!stage_is_cut(r) || cap == 0) return FRT_OK;
+    const int nbuf = r->ncuts >= 2 ? 2 : 1;
+    for (int st = 0; st < 2; ++st)
+        for (int k = 0; k < nbuf; ++k)
+            HIP_TRY(hipMalloc((void**)&r->d_qwords[st][k], (size_t)(st == 0 ? kContWordsPath : kContWordsSpatial) * cap * sizeof(uint32_t)));
+    return FRT_OK;
+}
+static int init_tile_state(frt_renderer* r) {
+    if (!r->d_tiles) return FRT_OK;
+    uint32_t init[2 * kTileStateWords] = {0};
+    init[0] = 1u; init[kTileStateWords] = 1u;   // first launch: bottom tile row first (floors cost more than ceilings and skies)
+    HIP_TRY(hipMemcpyAsync(r->d_tiles, init, sizeof(init), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return FRT_OK;
 }
 
 static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_opts* o) {
@@ -343,13 +432,19 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     HIP_TRY(hipSetDevice(r->device));
     if (o && (o->stream || (o->flags & FRT_FLAG_USE_STREAM))) { r->stream = (hipStream_t)o->stream; r->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); r->own_stream = true; }
-    if (r->flags & FRT_FLAG_OVERLAP_POST) {
-        HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&r->ev_spatial, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&r->ev_post, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&r->ev_smain, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&r->ev_scont, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&r->ev_tmain, hipEventDisableTiming));
+    if ((r->flags & FRT_FLAG_PIPELINE) && !(r->flags & FRT_FLAG_COMPACTION)) {   // (the compacting kernels keep the fused temporal stage: nothing to run ahead)
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        int prio = (lo + hi) / 2;
+        if (const char* e = getenv("FRT_AHEAD_PRIO")) prio = !strcmp(e, "low") ? lo : (!strcmp(e, "high") ? hi : prio);   // experiment knob
+        HIP_TRY(hipStreamCreateWithPriority(&r->ahead, hipStreamNonBlocking, prio));
+        HIP_TRY(hipStreamCreateWithPriority(&r->edge, hipStreamNonBlocking, prio));
+        for (hipEvent_t* e : {&r->ev_spix, &r->ev_tt, &r->ev_tail, &r->ev_tm, &r->ev_edge}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        // Measured (profiles/r2_schedule_notes.md): starting the ahead work behind T-merge, i.e. beside the spatial PIXEL kernel, beats
+        // starting it behind that kernel at every size (1080p frame 2.20 vs 2.43 ms, 1/8 strip 0.52 vs 0.72 ms): the two pixel kernels
+        // share the wave slots from the start, finish together, and the two latency-bound continuation tails then run side by side.
+        r->ahead_early = true;
+        if (const char* e = getenv("FRT_AHEAD_AFTER")) r->ahead_early = !strcmp(e, "tm");   // experiment knob: tm | spix
     }
     r->arena_bytes = arena_layout(r->W, r->H, r->off);
     if (o && o->device_arena) {
@@ -359,40 +454,44 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     } else {
         HIP_TRY(hipMalloc((void**)&r->arena, r->arena_bytes)); r->own_arena = true;
     }
-    HIP_TRY(hipMalloc((void**)&r->d_counters, 9 * sizeof(unsigned long long)));   // 4 stages x {closest, any} + halo overflow
-    {   // continuation queues (worst case: every pixel parks) and the bounce depths at which paths are cut
-        r->qcap = r->W * std::min(r->H, (r->re - r->rb) + 2u * kHaloSpatial);   // worst case: every traced pixel parks
-        HIP_TRY(hipMalloc((void**)&r->d_qwords, 4 * (size_t)kContWordsSpatial * r->qcap * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&r->d_qcount, 2 * (kMaxCuts + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&r->d_counters, C_COUNT * sizeof(unsigned long long)));
+    {   // the bounce depths at which paths are cut, and the continuation queues
         // Parking pays when the launch saturates the chip (>= ~0.6 M pixels: +6 % at 1080p, +5 % at half a frame); a thin strip
-        // is bound by the latency of its longest path and the extra launch only adds to it (tools/strip_time.py: 0.79 vs 0.70 ms
-        // for 1/8 of a 1080p frame), so thin strips run uncut.
+        // is bound by the latency of its longest path and the extra launch only adds to it (tools/strip_time.py), so thin strips run uncut.
         if ((size_t)r->W * (r->re - r->rb) < 600000u) r->ncuts = 0;
-        if (const char* e = getenv("FRT_PAIR")) r->pair_tail = atoi(e) != 0;   // experiment knob
-        {   // tile-row orders of the two traced stages; frame 0 starts bottom row first (floors cost more than ceilings and skies)
-            uint32_t rows[8];
-            phase_rows(r, rows);
-            for (int k = 0; k < 2; ++k) r->ntiles[k] = (rows[2 * (k + 1) + 1] - rows[2 * (k + 1)] + 15u) / 16u;
-            if (r->ntiles[0] <= 1024u && r->ntiles[1] <= 1024u && !getenv("FRT_NO_TILE_ORDER")) {   // (the variable is an experiment knob: rows top to bottom)
-                const size_t total = 2 * ((size_t)r->ntiles[0] + r->ntiles[1]);
-                HIP_TRY(hipMalloc((void**)&r->d_tiles, total * sizeof(uint32_t)));
-                std::vector<uint32_t> init(total, 0u);
-                size_t o = 0;
-                for (int k = 0; k < 2; ++k) { for (uint32_t i = 0; i < r->ntiles[k]; ++i) init[o + i] = r->ntiles[k] - 1u - i; o += 2 * (size_t)r->ntiles[k]; }
-                HIP_TRY(hipMemcpy(r->d_tiles, init.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
-            }
-        }
         if (const char* e = getenv("FRT_CUTS")) {   // experiment knob: comma-separated ascending depths, "0" = never cut
             r->ncuts = 0;
+            uint32_t last = 0;
             for (const char* p = e; *p && r->ncuts < (uint32_t)kMaxCuts;) {
-                uint32_t v = (uint32_t)strtoul(p, (char**)&p, 10);
-                if (v >= 1) r->cuts[r->ncuts++] = v;
-                if (*p == ',') ++p;
+                char* end = nullptr;
+                const unsigned long v = strtoul(p, &end, 10);
+                if (end == p) break;                                   // not a number: stop parsing (never loops on "abc" or "3;5")
+                if (v >= 1 && v > last && v < 0xFFFFu) { r->cuts[r->ncuts++] = (uint32_t)v; last = (uint32_t)v; }   // ascending only; others are skipped
+                p = end;
+                if (*p == ',') ++p; else break;
             }
+        }
+        r->qcap_max = r->W * std::min(r->H, (r->re - r->rb) + 2u * kHaloSpatial);   // every traced pixel parks
+        // Default capacity from the share of paths that reach the first cut (Cornell Box, oracle counts per pixel: 0.65 / 0.50 / 0.11
+        // alive at depth 1 / 2 / 3): generous, but not the worst case — a full queue is not an error (run_segment_and_park), and
+        // frt_renderer_stats grows a queue that overflowed.
+        const uint32_t c0 = r->ncuts ? r->cuts[0] : 0u;
+        const double share = c0 >= 3 ? 0.25 : (c0 == 2 ? 0.6 : 0.8);
+        uint32_t cap = (uint32_t)std::min<double>(r->qcap_max, std::max(4096.0, share * r->qcap_max));
+        if (o && o->queue_capacity) { cap = std::min(o->queue_capacity, r->qcap_max); r->qcap_fixed = true; }
+        if (const char* e = getenv("FRT_QUEUE_CAP")) { const long v = atol(e); if (v > 0) { cap = std::min<uint32_t>((uint32_t)v, r->qcap_max); r->qcap_fixed = true; } }
+        int rc = alloc_queues(r, cap);
+        if (rc) return rc;
+        HIP_TRY(hipMalloc((void**)&r->d_qcount, kQcountWords * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(r->d_qcount, 0, kQcountWords * sizeof(uint32_t), r->stream));
+        if (!getenv("FRT_NO_TILE_ORDER")) {   // (experiment knob: tile rows top to bottom)
+            HIP_TRY(hipMalloc((void**)&r->d_tiles, 2 * kTileStateWords * sizeof(uint32_t)));
+            rc = init_tile_state(r);
+            if (rc) return rc;
         }
     }
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));   // wgpu zero-initialises textures and buffers
-    HIP_TRY(hipMemsetAsync(r->d_counters, 0, 9 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_counters, 0, C_COUNT * sizeof(unsigned long long), r->stream));
     int rc = upload_scene(r, s->b);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -417,114 +516,238 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
     return r;
 }
 
-static int launch_deferred_post(frt_renderer* r) {
-    r->post_deferred = false;
-    frt_renderer::Timed t{};
+// ------------------------------------------------------------------------------------------------ frame schedule
+// Without FRT_FLAG_PIPELINE: one stream, G-buffer -> T-trace -> T-merge -> spatial -> post, in order.
+// With it, two streams:
+//   main  : T-merge(f) | spatial pixels(f) | spatial continuations(f) | post(f)          | T-merge(f+1) ...
+//   ahead :                                | G-buffer(f+1) | T-trace(f+1) pixels | T-trace(f+1) continuations |
+// T-trace depends on nothing of the previous frame (frt_path.hpp), so G-buffer + T-trace of frame f+1 are enqueued behind the spatial
+// PIXEL kernel of frame f and run beside its continuation launches and post — the latency-bound part of the frame, which leaves most of
+// the chip idle — instead of after them. (Beside the spatial pixel kernel itself nothing is gained: either pixel kernel fills every
+// wave slot of the chip on its own — measured, profiles/r2_schedule_notes.md — so two of them only take turns.)
+// The next frame's camera is not known yet: the renderer SPECULATES that it is this frame's camera with frame_count + 1 and
+// prev_view_proj = view_proj — what build_uniform produces for a camera that did not move (camera.rs:207-256, state.rs:172) — and
+// only while the camera has in fact been static for a frame. At the next render call the speculated 288 bytes are compared with the
+// real uniform: equal -> the work is adopted (its ray counts are committed by T-merge); different -> it is dropped (its buffers are
+// simply overwritten, its counts cleared) and the stages run in order on the main stream. Same pixels either way.
+// Buffer hazards: G-buffer slot (f+1)&1 and the candidate buffer are last read by T-merge(f) and post(f-1), the motion slot by post(f-1):
+// all on the main stream before spatial pixels(f), which the ahead stream waits for (ev_spix); everything else stays on the main stream.
+static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, TraceLaunch& L) {
+    memset(&L, 0, sizeof(L));
+    const bool cut = stage_is_cut(r) && r->qcap > 0;
+    L.ncuts = cut ? r->ncuts : 0u;
+    for (int k = 0; k < kMaxCuts; ++k) L.cuts[k] = r->cuts[k];
+    L.qwords[0] = r->d_qwords[stage - 1][0]; L.qwords[1] = r->d_qwords[stage - 1][1];
+    const uint32_t par = r->qparity[stage - 1];
+    uint32_t* base = r->d_qcount + (size_t)(stage - 1) * 2 * (kMaxCuts + 1);
+    L.counts = base + (size_t)par * (kMaxCuts + 1);
+    L.zero_counts = cut ? base + (size_t)(par ^ 1u) * (kMaxCuts + 1) : nullptr;
+    L.capacity = r->qcap;
+    L.overflow = r->d_qcount + 2 * 2 * (kMaxCuts + 1) + (stage - 1);
+    L.tile_state = (with_tile_state && r->d_tiles) ? r->d_tiles + (size_t)(stage - 1) * kTileStateWords : nullptr;
+}
+
+// G-buffer + T-trace over their rows on stream `q`; `pending` = count the rays in the pending slots (speculative work).
+static int launch_g_and_trace(frt_renderer* r, FrameView fv, hipStream_t q, bool do_g, bool do_tt, bool pending) {
+    uint32_t rows[8];
+    phase_rows(r, rows);
     const bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
-    if (timed) {
-        HIP_TRY(hipEventCreate(&t.a)); HIP_TRY(hipEventCreate(&t.b)); t.stage = 3;
-        HIP_TRY(hipEventRecord(t.a, r->side));
+    if (do_g) {
+        fv.y0 = rows[0]; fv.y1 = rows[1];
+        fv.ray_counters = r->d_counters + (pending ? C_PENDING : C_STAGE);
+        frt_renderer::Timed t{};
+        if (timed) { int rc = timer_begin(r, t, 0, q); if (rc) return rc; }
+        HIP_TRY(launch_gbuffer(r->sv, fv, q));
+        if (timed) { int rc = timer_end(r, t, q); if (rc) return rc; }
+        r->stats.launches[0] += 1;
     }
-    StageLaunch L{};
-    HIP_TRY(launch_stage(3, r->sv, r->post_fv, r->side, L));
-    if (timed) { HIP_TRY(hipEventRecord(t.b, r->side)); r->pending.push_back(t); }
-    HIP_TRY(hipEventRecord(r->ev_post, r->side));
-    r->post_in_flight = true;
-    r->stats.launches[3] += 1;
+    if (do_tt) {
+        fv.y0 = rows[2]; fv.y1 = rows[3];
+        fv.ray_counters = r->d_counters + (pending ? C_PENDING + 2 : C_STAGE + 2);
+        TraceLaunch L;
+        trace_launch_of(r, 1, true, L);
+        frt_renderer::Timed t{};
+        if (timed) { int rc = timer_begin(r, t, 1, q); if (rc) return rc; }
+        HIP_TRY(launch_trace_pixels(1, r->sv, fv, q, L));
+        if (trace_has_continuations(L, r->max_depth)) HIP_TRY(launch_trace_continuations(1, r->sv, fv, q, L));
+        if (timed) { int rc = timer_end(r, t, q); if (rc) return rc; }
+        r->qparity[0] ^= 1u;
+        r->stats.launches[1] += 1;
+    }
+    return FRT_OK;
+}
+
+static bool same_camera(const frt_camera_uniform& a, const frt_camera_uniform& b) { return memcmp(&a, &b, sizeof(a)) == 0; }
+// What build_uniform gives for the frame after `cam` when the camera does not move.
+static frt_camera_uniform next_static_camera(const frt_camera_uniform& cam) {
+    frt_camera_uniform n = cam;
+    memcpy(n.prev_view_proj, cam.view_proj, sizeof(n.prev_view_proj));
+    n.frame_count = cam.frame_count + 1u;
+    return n;
+}
+
+static int open_frame(frt_renderer* r, const frt_camera_uniform* cam) {
+    r->frame_open = true;
+    r->cur_cam = *cam;
+    r->g_done = r->tt_done = r->tm_done = r->s_started = r->s_inner_done = r->s_edge_done = false;
+    r->from_speculation = false;
+    r->camera_static = r->have_last_cam && same_camera(next_static_camera(r->last_cam), *cam);
+    if (r->spec_valid) {
+        r->spec_valid = false;
+        if (same_camera(r->spec_cam, *cam) && r->spec_frame == r->frame_count) {
+            r->g_done = r->tt_done = r->from_speculation = true;      // adopted: T-merge waits for ev_tt and commits the ray counts
+            r->motion_slot = r->spec_motion_slot;
+            r->stats.speculated_frames += 1;
+        } else {
+            // dropped: order the main stream behind it, clear its ray counts; its buffers are overwritten by the stages that follow
+            int rc = fence_ahead(r);
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(r->d_counters + C_PENDING, 0, 4 * sizeof(unsigned long long), r->stream));
+            r->stats.discarded_speculations += 1;
+        }
+    }
+    return FRT_OK;
+}
+
+// G-buffer + T-trace of the NEXT frame on the ahead stream, under the camera a static scene will present. Only for a camera that has
+// been static for a frame (a moving camera never matches). early: ordered behind T-merge (it reads the G-buffer slot and the candidate
+// buffer this work overwrites); otherwise behind every spatial pixel launch of this frame.
+static int launch_speculation(frt_renderer* r, const frt_camera_uniform* cam, bool early) {
+    if (!r->pipeline() || !r->camera_static || !r->tm_done || r->spec_valid) return FRT_OK;
+    hipEvent_t ev = r->ev_tm;
+    if (!early) { ev = r->ev_spix; HIP_TRY(hipEventRecord(r->ev_spix, r->stream)); }
+    r->spec_cam = next_static_camera(*cam);
+    r->spec_frame = r->frame_count + 1u;
+    r->spec_motion_slot = r->motion_slot ^ 1u;
+    FrameView fa;
+    fill_frame_view(r, &r->spec_cam, r->spec_frame, r->spec_motion_slot, fa);
+    HIP_TRY(hipStreamWaitEvent(r->ahead, ev, 0));
+    int rc = launch_g_and_trace(r, fa, r->ahead, true, true, true);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(r->ev_tt, r->ahead));
+    r->tail_pending = true;
+    r->spec_valid = true;
     return FRT_OK;
 }
 
 int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, int phases) {
     if (!r || !cam) return fail(FRT_ERR_INVALID_ARG, "render: null");
+    if ((r->jitter[0] != 0.0f || r->jitter[1] != 0.0f) && !(r->rb == 0 && r->re == r->H) && (phases & FRT_PHASE_POST))
+        return fail(FRT_ERR_INVALID_ARG, "render: a non-zero post jitter (bilinear taps with Repeat addressing) is not supported by strip renderers");
     HIP_TRY(hipSetDevice(r->device));
-    FrameView fv;
-    fill_frame_view(r, cam, fv);
-    if (phases & FRT_PHASE_GBUFFER) r->motion_slot = (r->side && (r->frame_count & 1u)) ? 1u : 0u;
+    if (!r->frame_open) { int rc = open_frame(r, cam); if (rc) return rc; }
+    const bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
+    const bool compaction = (r->flags & FRT_FLAG_COMPACTION) != 0;
     uint32_t rows[8];
     phase_rows(r, rows);
-    for (int stage = 0; stage < 4; ++stage) {
-        if (!(phases & (1 << stage))) continue;
-        fv.y0 = rows[2 * stage]; fv.y1 = rows[2 * stage + 1];
-        fv.ray_counters = r->d_counters + 2 * stage;
-        hipStream_t q = r->stream;
-        // Side-stream schedule (FRT_FLAG_OVERLAP_POST). The two latency-bound tails of a frame leave the GPU mostly idle, and the two
-        // stages off the temporal -> spatial -> temporal chain are put there:
-        //   main: G(f+1) | wait S-cont(f) | T-pixel(f+1) | T-cont(f+1)          | wait post(f) | S-pixel(f+1) ...
-        //   side: S-cont(f) ............. |               | post(f), deferred    |              | S-cont(f+1) ...
-        // G-buffer(f+1) depends on nothing of frame f; post(f) needs spatial(f) complete and must finish before S-pixel(f+1)
-        // overwrites the radiance. post(f) is therefore not launched when it is requested but behind the temporal pixel kernel
-        // of the next frame (or at the next sync / read / reset, whichever comes first).
-        if (r->side && (stage == 2 || stage == 3) && r->post_deferred) { int rc_ = launch_deferred_post(r); if (rc_) return rc_; }
-        if (r->side && stage == 3) {   // post(f) after spatial(f): its pixel kernel (main) and its continuation (side, in order)
-            HIP_TRY(hipEventRecord(r->ev_spatial, r->stream));
-            HIP_TRY(hipStreamWaitEvent(r->side, r->ev_spatial, 0));
-            q = r->side;
-            const bool traced_cut = r->ncuts > 0 && r->cuts[0] < r->max_depth && !(r->flags & FRT_FLAG_COMPACTION);
-            if (traced_cut) { r->post_deferred = true; r->post_fv = fv; continue; }   // no temporal continuation to hide behind otherwise
+    FrameView fv;
+
+    // ---- G-buffer, T-trace: on the main stream unless they already ran ahead of the frame
+    const bool want_g = (phases & FRT_PHASE_GBUFFER) && !r->g_done;
+    const bool want_tt = (phases & FRT_PHASE_TEMPORAL) && !r->tt_done && !compaction;
+    if (want_g || want_tt) {
+        int rc = fence_ahead(r);      // (a dropped speculation may still be writing the slots these stages write)
+        if (rc) return rc;
+        if (want_g) r->motion_slot = r->pipeline() ? (r->motion_slot ^ 1u) : 0u;
+        fill_frame_view(r, cam, r->frame_count, r->motion_slot, fv);
+        rc = launch_g_and_trace(r, fv, r->stream, want_g, want_tt, false);
+        if (rc) return rc;
+        if (want_g) r->g_done = true;
+        if (want_tt) r->tt_done = true;
+    }
+    // ---- T-merge (or the fused temporal stage of the compacting kernels)
+    if ((phases & FRT_PHASE_TEMPORAL) && !r->tm_done) {
+        fill_frame_view(r, cam, r->frame_count, r->motion_slot, fv);
+        fv.y0 = rows[2]; fv.y1 = rows[3];
+        if (compaction) {
+            fv.ray_counters = r->d_counters + C_STAGE + 2;
+            frt_renderer::Timed t{};
+            if (timed) { int rc = timer_begin(r, t, 1, r->stream); if (rc) return rc; }
+            HIP_TRY(launch_compact(1, r->sv, fv, r->stream));
+            if (timed) { int rc = timer_end(r, t, r->stream); if (rc) return rc; }
+            r->stats.launches[1] += 1;
+        } else {
+            if (r->from_speculation) HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_tt, 0));
+            frt_renderer::Timed t{};
+            if (timed) { int rc = timer_begin(r, t, 4, r->stream); if (rc) return rc; }
+            HIP_TRY(launch_merge(r->sv, fv, r->stream, r->from_speculation ? r->d_counters + C_PENDING : nullptr, r->d_counters + C_STAGE));
+            if (timed) { int rc = timer_end(r, t, r->stream); if (rc) return rc; }
+            if (r->pipeline()) HIP_TRY(hipEventRecord(r->ev_tm, r->stream));
         }
-        if (r->side && (stage == 1 || stage == 2) && r->scont_in_flight) {
-            HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_scont, 0));
-            r->scont_in_flight = false;
+        r->tm_done = true;
+    }
+    // ---- spatial + shade: pixels (whole, or interior / edge rows separately), then the continuations
+    const int sp = ((phases & FRT_PHASE_SPATIAL) ? (FRT_PHASE_SPATIAL_INNER | FRT_PHASE_SPATIAL_EDGE) : 0) | (phases & (FRT_PHASE_SPATIAL_INNER | FRT_PHASE_SPATIAL_EDGE));
+    if (sp) {
+        if (!r->s_started) {
+            r->s_started = true;
+            if (r->ahead_early) { int rc = launch_speculation(r, cam, true); if (rc) return rc; }
+            r->s_timed = false;
+            if (timed) { int rc = timer_begin(r, r->s_timer, 2, r->stream); if (rc) return rc; r->s_timed = true; }
         }
-        if (r->side && stage == 2 && r->post_in_flight) {   // spatial(f+1) overwrites the radiance post(f) reads
-            HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0));
-            r->post_in_flight = false;
-        }
-        const bool traced_cut_stage = (stage == 1 || stage == 2) && r->ncuts > 0 && r->cuts[0] < r->max_depth && !(r->flags & FRT_FLAG_COMPACTION);
-        if (traced_cut_stage) {   // this stage's segment counters must be zero (after the waits: the previous frame's tail used them)
-            if (!r->counts_clean[stage - 1])
-                HIP_TRY(hipMemsetAsync(r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1), 0, (kMaxCuts + 1) * sizeof(uint32_t), r->stream));
-            r->counts_clean[stage - 1] = false;   // about to be used
-        }
-        frt_renderer::Timed t{};
-        bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
-        if (timed) {
-            HIP_TRY(hipEventCreate(&t.a)); HIP_TRY(hipEventCreate(&t.b)); t.stage = stage;
-            HIP_TRY(hipEventRecord(t.a, q));
-        }
-        StageLaunch L{};
-        L.compaction = (r->flags & FRT_FLAG_COMPACTION) != 0;
-        L.pair_tail = r->pair_tail;
-        L.ncuts = r->ncuts;
-        for (int k = 0; k < kMaxCuts; ++k) L.cuts[k] = r->cuts[k];
-        if (stage == 1 || stage == 2) {
-            size_t qsz = (size_t)kContWordsSpatial * r->qcap;
-            for (int k = 0; k < 2; ++k) L.qwords[k] = r->d_qwords + (size_t)(2 * (stage - 1) + k) * qsz;
-            L.counts = r->d_qcount + (size_t)(stage - 1) * (kMaxCuts + 1);
-            L.capacity = r->qcap;
-            if (r->d_tiles) {
-                uint32_t* p = r->d_tiles;
-                for (int k = 0; k < 2; ++k) { L.row_order[k] = p; L.row_cost[k] = p + r->ntiles[k]; L.nrows[k] = r->ntiles[k]; p += 2 * (size_t)r->ntiles[k]; }
+        fill_frame_view(r, cam, r->frame_count, r->motion_slot, fv);
+        fv.ray_counters = r->d_counters + C_STAGE + 4;
+        const uint32_t y0 = rows[4], y1 = rows[5];
+        const bool was_complete = r->s_inner_done && r->s_edge_done;
+        TraceLaunch L;
+        memset(&L, 0, sizeof(L));
+        if (compaction) {
+            if (!r->s_inner_done) { fv.y0 = y0; fv.y1 = y1; HIP_TRY(launch_compact(2, r->sv, fv, r->stream)); }
+            r->s_inner_done = r->s_edge_done = true;
+        } else {
+            uint32_t ia, ib;
+            spatial_inner_rows(r, y0, y1, ia, ib);
+            if ((sp & FRT_PHASE_SPATIAL_INNER) && !r->s_inner_done) {
+                trace_launch_of(r, 2, true, L);
+                fv.y0 = ia; fv.y1 = ib;
+                HIP_TRY(launch_trace_pixels(2, r->sv, fv, r->stream, L));
+                r->s_inner_done = true;
+            }
+            if ((sp & FRT_PHASE_SPATIAL_EDGE) && !r->s_edge_done) {
+                trace_launch_of(r, 2, false, L);
+                uint32_t* const zc = L.zero_counts;
+                bool need_clear = ia >= ib;        // otherwise the interior launch clears the next launch's counters
+                const uint32_t edge[2][2] = {{y0, ia}, {ib, y1}};
+                // Pipeline: on their own stream, beside the interior launch (two launches in one stream would run one after the other,
+                // and a thin strip's launch lasts as long as its longest path whatever its size). The caller has ordered that stream behind
+                // the halo exchange (frt_renderer_stream(r, 2)); here it is ordered behind T-merge.
+                hipStream_t q = r->stream;
+                const bool any_edge = (ia > y0) || (y1 > ib);
+                if (r->edge && any_edge && ia < ib) { q = r->edge; HIP_TRY(hipStreamWaitEvent(r->edge, r->ev_tm, 0)); }
+                for (const auto& e : edge) {
+                    if (e[1] <= e[0]) continue;
+                    L.zero_counts = need_clear ? zc : nullptr;
+                    need_clear = false;
+                    fv.y0 = e[0]; fv.y1 = e[1];
+                    HIP_TRY(launch_trace_pixels(2, r->sv, fv, q, L));
+                }
+                if (q != r->stream) { HIP_TRY(hipEventRecord(r->ev_edge, r->edge)); r->edge_in_flight = true; }
+                r->s_edge_done = true;
             }
         }
-        // Clearing the counters in passing saves the two memsets per frame (each sits between two dependent kernels): the temporal
-        // pixel kernel clears the spatial stage's counters (the main stream has waited for the previous spatial continuation by
-        // then), the row-order kernel behind the spatial pixel kernel clears the temporal stage's for the next frame.
-        const bool sort_runs = stage == 2 && traced_cut_stage && L.row_cost[0] && L.row_cost[1];
-        if (stage == 1 && traced_cut_stage) L.zero_in_pixel = r->d_qcount + (size_t)(kMaxCuts + 1);
-        if (sort_runs) L.zero_in_sort = r->d_qcount;
-        bool has_cont = false;
-        const bool tail_on_side = r->side && stage == 2;
-        hipEvent_t ev = tail_on_side ? r->ev_smain : ((r->side && stage == 1 && r->post_deferred) ? r->ev_tmain : nullptr);
-        HIP_TRY(launch_stage(stage, r->sv, fv, q, L, tail_on_side ? r->side : nullptr, ev, &has_cont));
-        if (stage == 1 && traced_cut_stage) r->counts_clean[1] = true;
-        if (sort_runs) r->counts_clean[0] = true;
-        const bool on_side = tail_on_side && has_cont;
-        if (on_side) { HIP_TRY(hipEventRecord(r->ev_scont, r->side)); r->scont_in_flight = true; }
-        if (timed) { HIP_TRY(hipEventRecord(t.b, on_side ? r->side : q)); r->pending.push_back(t); }
-        if (r->side && stage == 3) { HIP_TRY(hipEventRecord(r->ev_post, r->side)); r->post_in_flight = true; }
-        if (r->side && stage == 1 && r->post_deferred) {   // post(f) behind T-pixel(f+1): it runs while T-cont(f+1) leaves the GPU idle
-            if (has_cont) HIP_TRY(hipStreamWaitEvent(r->side, r->ev_tmain, 0));
-            int rc_ = launch_deferred_post(r);
-            if (rc_) return rc_;
+        if (r->s_inner_done && r->s_edge_done && !was_complete) {
+            if (r->edge_in_flight) { HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_edge, 0)); r->edge_in_flight = false; }
+            // every pixel launch of the stage is enqueued: the next frame's G-buffer + T-trace may start behind them
+            if (!r->ahead_early) { int rc = launch_speculation(r, cam, false); if (rc) return rc; }
+            if (!compaction) {
+                trace_launch_of(r, 2, false, L);
+                fv.y0 = y0; fv.y1 = y1;
+                if (trace_has_continuations(L, r->max_depth)) HIP_TRY(launch_trace_continuations(2, r->sv, fv, r->stream, L));
+                r->qparity[1] ^= 1u;
+            }
+            if (r->s_timed) { int rc = timer_end(r, r->s_timer, r->stream); if (rc) return rc; r->s_timed = false; }
+            r->stats.launches[2] += 1;
         }
-        if (r->side && stage == 1 && r->post_in_flight) {
-            // whatever the caller enqueues next on the main stream (the halo exchange of the previous accumulation rows, then
-            // spatial) must see post(f) finished
-            HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0));
-            r->post_in_flight = false;
-        }
-        r->stats.launches[stage] += 1;
+    }
+    // ---- post / accumulate (main stream: it runs while the ahead stream is in the latency-bound tail of the next frame's T-trace)
+    if (phases & FRT_PHASE_POST) {
+        fill_frame_view(r, cam, r->frame_count, r->motion_slot, fv);
+        fv.y0 = rows[6]; fv.y1 = rows[7];
+        frt_renderer::Timed t{};
+        if (timed) { int rc = timer_begin(r, t, 3, r->stream); if (rc) return rc; }
+        HIP_TRY(launch_post(fv, r->stream));
+        if (timed) { int rc = timer_end(r, t, r->stream); if (rc) return rc; }
+        r->stats.launches[3] += 1;
     }
     return FRT_OK;
 }
@@ -532,6 +755,8 @@ int frt_renderer_end_frame(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "end_frame: null");
     r->frame_count += 1;   // renderer.rs:515
     r->stats.frames += 1;
+    if (r->frame_open) { r->last_cam = r->cur_cam; r->have_last_cam = true; }
+    r->frame_open = false;
     return FRT_OK;
 }
 int frt_renderer_render(frt_renderer* r, const frt_camera_uniform* cam) {
@@ -539,24 +764,39 @@ int frt_renderer_render(frt_renderer* r, const frt_camera_uniform* cam) {
     if (rc) return rc;
     return frt_renderer_end_frame(r);
 }
+int frt_renderer_set_jitter(frt_renderer* r, float jx, float jy) {
+    if (!r) return fail(FRT_ERR_INVALID_ARG, "set_jitter: null");
+    r->jitter[0] = jx; r->jitter[1] = jy;
+    return FRT_OK;
+}
+int frt_renderer_render_jittered(frt_renderer* r, const frt_camera_uniform* cam, float jx, float jy) {
+    int rc = frt_renderer_set_jitter(r, jx, jy);
+    if (rc) return rc;
+    return frt_renderer_render(r, cam);
+}
 int frt_renderer_sync(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "sync: null");
     HIP_TRY(hipSetDevice(r->device));
     return sync_all(r);
 }
+int frt_renderer_fence(frt_renderer* r) {
+    if (!r) return fail(FRT_ERR_INVALID_ARG, "fence: null");
+    HIP_TRY(hipSetDevice(r->device));
+    return fence_ahead(r);
+}
+void* frt_renderer_stream(const frt_renderer* r, int which) {
+    if (!r) return nullptr;
+    if (which == 1 && r->ahead) return (void*)r->ahead;
+    if (which == 2 && r->edge) return (void*)r->edge;
+    return (void*)r->stream;
+}
 uint32_t frt_renderer_frame_count(const frt_renderer* r) { return r ? r->frame_count : 0u; }
 int frt_renderer_reset(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "reset: null");
-    // The side-stream schedule relies on the ping-pong slots alternating from frame to frame; a reset breaks the alternation (the
-    // next frame may write the slot the in-flight tail of the last frame still reads), so the main stream first waits for that tail.
-    // Stream-level only: the reference resets every frame while the camera moves (state.rs:152), this must stay asynchronous.
-    if (r->side) {
-        HIP_TRY(hipSetDevice(r->device));
-        if (r->post_deferred) { int rc_ = launch_deferred_post(r); if (rc_) return rc_; }
-        if (r->scont_in_flight) { HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_scont, 0)); r->scont_in_flight = false; }
-        if (r->post_in_flight) { HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_post, 0)); r->post_in_flight = false; }
-    }
+    // Only the counter restarts (state.rs:152: every frame while the camera moves), asynchronously. A speculated next frame no longer
+    // matches (its frame_count) and is dropped by the next render call, which also orders the main stream behind the ahead stream.
     r->frame_count = 0;
+    r->frame_open = false;
     return FRT_OK;
 }
 int frt_renderer_clear(frt_renderer* r) {
@@ -566,9 +806,14 @@ int frt_renderer_clear(frt_renderer* r) {
     int rc = resolve_timing(r);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));
-    HIP_TRY(hipMemsetAsync(r->d_counters, 0, 9 * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_counters, 0, C_COUNT * sizeof(unsigned long long), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_qcount, 0, kQcountWords * sizeof(uint32_t), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
+    rc = init_tile_state(r);
+    if (rc) return rc;
     r->frame_count = 0;
+    r->frame_open = false; r->spec_valid = false; r->have_last_cam = false; r->camera_static = false;
+    r->qparity[0] = r->qparity[1] = 0; r->motion_slot = 0;
     memset(&r->stats, 0, sizeof(r->stats));
     return FRT_OK;
 }
@@ -583,6 +828,7 @@ static int buf_index(const frt_renderer* r, int buf, int index) {
     case FRT_BUF_RAW: return B_RAW;
     case FRT_BUF_DISPLAY: return B_DISP;
     case FRT_BUF_ACCUM: return B_ACC0 + (index & 1);
+    case FRT_BUF_CANDIDATE: return B_CAND;
     }
     return -1;
 }
@@ -636,14 +882,26 @@ int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
     { int rc_ = sync_all(r); if (rc_) return rc_; }
     int rc = resolve_timing(r);
     if (rc) return rc;
-    unsigned long long c[9] = {0};
+    unsigned long long c[C_COUNT] = {0};
     HIP_TRY(hipMemcpy(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-    r->stats.halo_overflow = c[8];
+    r->stats.halo_overflow = c[C_HALO];
     r->stats.rays_closest = 0; r->stats.rays_any = 0;
     for (int st = 0; st < 4; ++st) {
         r->stats.rays_stage[st][0] = c[2 * st]; r->stats.rays_stage[st][1] = c[2 * st + 1];
         r->stats.rays_closest += c[2 * st]; r->stats.rays_any += c[2 * st + 1];
     }
+    // queues that overflowed since the last call (paths were finished in place, nothing was lost): grow them while the GPU is idle
+    uint32_t ov[2] = {0, 0};
+    HIP_TRY(hipMemcpy(ov, r->d_qcount + 2 * 2 * (kMaxCuts + 1), sizeof(ov), hipMemcpyDeviceToHost));
+    if (ov[0] || ov[1]) {
+        r->stats.queue_overflow += (uint64_t)ov[0] + ov[1];
+        HIP_TRY(hipMemset(r->d_qcount + 2 * 2 * (kMaxCuts + 1), 0, sizeof(ov)));
+        if (!r->qcap_fixed && r->qcap < r->qcap_max) {
+            rc = alloc_queues(r, (uint32_t)std::min<uint64_t>(r->qcap_max, (uint64_t)r->qcap * 2u));
+            if (rc) return rc;
+        }
+    }
+    r->stats.queue_capacity = r->qcap;
     *out = r->stats;
     return FRT_OK;
 }

@@ -391,12 +391,13 @@ void create_restir_scene(SceneBuilder& b) {
 } // namespace scenes
 
 // ---------------------------------------------------------------------------------------------- camera.rs
-void camera_default(float aspect, uint32_t frame_count, uint32_t num_lights, frt_camera_uniform* out) {
-    // CameraController::new (camera.rs:40-42) + build_uniform (:207-256), jitter = 0 (:202-203), prev_view_proj = IDENTITY
-    // on the first call -> the unjittered view_proj; with a static camera it stays that value (state.rs:172).
-    const float eye[3] = {0.0f, 0.0f, 3.0f};
+// CameraController::build_uniform (camera.rs:207-256) for any pose, jitter and previous view-projection.
+// prev_view_proj == null stands for the controller's initial Mat4::IDENTITY ("first frame": the unjittered view_proj is sent, :233-238).
+// unjittered_out (may be null) receives the second tuple element, which State stores as the next frame's prev_view_proj (state.rs:172).
+void camera_build_uniform(const float position[3], float yaw, float pitch, const float* prev_view_proj, float aspect, uint32_t frame_count,
+                          uint32_t num_lights, float jitter_x, float jitter_y, frt_camera_uniform* out, float* unjittered_out) {
+    const float eye[3] = {position[0], position[1], position[2]};
     const float rad_per_deg = 3.14159265358979323846f / 180.0f;
-    float yaw = -90.0f * rad_per_deg, pitch = 0.0f;
     float fwd[3] = {cosf(pitch) * cosf(yaw), sinf(pitch), cosf(pitch) * sinf(yaw)};
     v3_normalize_glam(fwd);
     // Mat4::look_at_rh(eye, eye + fwd, Y) -> look_to_rh(eye, (eye + fwd) - eye, Y)
@@ -412,14 +413,38 @@ void camera_default(float aspect, uint32_t frame_count, uint32_t num_lights, frt
     // Mat4::perspective_rh(45 deg, aspect, 0.1, 100): depth 0..1
     float half = 0.5f * (45.0f * rad_per_deg);
     float hh = cosf(half) / sinf(half), ww = hh / aspect, rr = 100.0f / (0.1f - 100.0f);
-    Mat4 proj{};
-    proj.m[0] = ww; proj.m[5] = hh; proj.m[10] = rr; proj.m[11] = -1.0f; proj.m[14] = rr * 0.1f;
+    Mat4 proj_base{};
+    proj_base.m[0] = ww; proj_base.m[5] = hh; proj_base.m[10] = rr; proj_base.m[11] = -1.0f; proj_base.m[14] = rr * 0.1f;
+    Mat4 vp_unjittered = mat4_mul(proj_base, view);
+    Mat4 proj = proj_base;
+    proj.m[8] += jitter_x;      // proj_cols[2][0] += jitter.0 (:226): shear of the projection
+    proj.m[9] += jitter_y;      // proj_cols[2][1] += jitter.1 (:227)
     Mat4 vp = mat4_mul(proj, view), vi = mat4_inverse(view), pi = mat4_inverse(proj);
     memset(out, 0, sizeof(*out));
     memcpy(out->view_proj, vp.m, 64); memcpy(out->view_inverse, vi.m, 64); memcpy(out->proj_inverse, pi.m, 64);
-    memcpy(out->prev_view_proj, vp.m, 64);
+    memcpy(out->prev_view_proj, prev_view_proj ? prev_view_proj : vp_unjittered.m, 64);
     out->view_pos[0] = eye[0]; out->view_pos[1] = eye[1]; out->view_pos[2] = eye[2]; out->view_pos[3] = 1.0f;
     out->frame_count = frame_count; out->num_lights = num_lights;
+    if (unjittered_out) memcpy(unjittered_out, vp_unjittered.m, 64);
+}
+// CameraController::get_halton_jitter (camera.rs:182-205). The reference multiplies the Halton offsets by 0 (:202-203) — `scale`
+// stands for that literal: 0 reproduces the shipped reference, 1 is the sequence the comment above it describes.
+void camera_halton_jitter(uint32_t index, uint32_t width, uint32_t height, float scale, float out[2]) {
+    auto halton = [](uint32_t i, uint32_t base) {
+        float f = 1.0f, r = 0.0f;
+        while (i > 0) { f /= (float)base; r += f * (float)(i % base); i /= base; }
+        return r;
+    };
+    float hx = halton(index + 1u, 2u) - 0.5f, hy = halton(index + 1u, 3u) - 0.5f;
+    out[0] = (hx * scale) / (float)width;
+    out[1] = (hy * scale) / (float)height;
+}
+void camera_default(float aspect, uint32_t frame_count, uint32_t num_lights, frt_camera_uniform* out) {
+    // CameraController::new (camera.rs:40-42) + build_uniform (:207-256), jitter = 0 (:202-203), prev_view_proj = IDENTITY
+    // on the first call -> the unjittered view_proj; with a static camera it stays that value (state.rs:172).
+    const float eye[3] = {0.0f, 0.0f, 3.0f};
+    const float rad_per_deg = 3.14159265358979323846f / 180.0f;
+    camera_build_uniform(eye, -90.0f * rad_per_deg, 0.0f, nullptr, aspect, frame_count, num_lights, 0.0f, 0.0f, out, nullptr);
 }
 
 } // namespace frt

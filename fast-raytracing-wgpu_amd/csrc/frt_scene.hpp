@@ -125,6 +125,9 @@ void create_restir_scene(SceneBuilder& b);   // scenes.rs:133-223
 
 // src/camera.rs:207-256 at the initial pose
 void camera_default(float aspect, uint32_t frame_count, uint32_t num_lights, frt_camera_uniform* out);
+void camera_build_uniform(const float position[3], float yaw, float pitch, const float* prev_view_proj, float aspect, uint32_t frame_count,
+                          uint32_t num_lights, float jitter_x, float jitter_y, frt_camera_uniform* out, float* unjittered_out);
+void camera_halton_jitter(uint32_t index, uint32_t width, uint32_t height, float scale, float out[2]);
 
 } // namespace frt
 

@@ -22,6 +22,7 @@ struct FrameView {
     float2* gmotion;
     ReservoirView* res_temporal;     // reservoir_buffers[0]
     ReservoirView* res_spatial;      // reservoir_buffers[1]
+    float4* cand;                    // temporal candidate record (v1_pos, p_hat): T-trace -> T-merge (frt_path.hpp)
     uint2* raw;                      // rgba16f
     uint32_t* display;               // rgba8
     const float4* history; float4* accum;
@@ -30,6 +31,7 @@ struct FrameView {
     uint32_t own_y0, own_y1;         // rows whose rays are counted (a strip's redundant halo rows are not)
     uint32_t prev_y0, prev_y1;       // rows whose previous-frame reservoirs / G-buffer are valid here (whole frame: 0, H)
     unsigned long long* overflow;    // counts previous-frame reads outside them (may be null)
+    float jitter_x, jitter_y;        // PostParams.jitter (renderer.rs:14, :376); (0, 0) in the shipped reference (camera.rs:202-203)
     CameraView cam;
 };
 
@@ -370,7 +372,10 @@ FRT_HD void gbuffer_pixel(PathCtx& c, uint32_t px, uint32_t py) {
 }
 
 // ================================================================================================ stage 3
-// post.wgsl:61-282. jitter == 0 (camera.rs:202-203): textureSampleLevel(raw_tex / albedo_tex) lands on texel centres -> texel fetch.
+// post.wgsl:61-282. The centre / neighbour colour and albedo are textureSampleLevel(raw_tex / albedo_tex, smp, uv + unjitter_offset)
+// (post.wgsl:72-78, :97-109, :152-158) under the Repeat / Linear sampler of renderer.rs:240-249. Contract: with jitter == (0, 0)
+// (the shipped reference, camera.rs:202-203) the sample point is the texel centre and the sample IS the texel (what a sampler's
+// fixed-point weights give); otherwise f32 bilinear on texel centres with Repeat addressing, like sample_layer above.
 FRT_HD float gauss(float x, float sigma) {   // post.wgsl:21-26 (sigma >= 0.001 at every call site)
     return expf_(-(x * x) * (1.0f / (2.0f * sigma * sigma)));   // x / c evaluated as x * (1 / c) (contract); sigma is a constant
 }
@@ -399,6 +404,51 @@ struct GlobalTaps {
     const FrameView& fv;
     FRT_HD TapData get(int nx, int ny) const { return decode_tap(fv, (uint32_t)ny * fv.W + (uint32_t)nx); }
     FRT_HD f3 color(int nx, int ny) const { return xyz(unpack_rgba16f(fv.raw[(uint32_t)ny * fv.W + (uint32_t)nx])); }
+};
+// jitter != 0: bilinear taps of the radiance and albedo targets at uv + unjitter_offset; normal and position stay texel loads
+// (post.wgsl:80-83, :111-113). Straight from HBM: the jittered path is dead in the shipped reference and is not tuned.
+struct JitterTaps {
+    const FrameView& fv;
+    struct Foot { uint32_t i00, i10, i01, i11; float ax, ay; };
+    FRT_HD Foot foot(int nx, int ny) const {
+        f2 size = mk2((float)fv.W, (float)fv.H);
+        f2 uv = (mk2((float)nx, (float)ny) + mk2(0.5f, 0.5f)) / size;
+        f2 unjitter_offset = mk2(-fv.jitter_x, fv.jitter_y) * 0.5f;   // post.wgsl:73
+        f2 sample_uv = uv + unjitter_offset;
+        float x = sample_uv.x * size.x - 0.5f, y = sample_uv.y * size.y - 0.5f;
+        float fx = floorf_(x), fy = floorf_(y);
+        int W = (int)fv.W, H = (int)fv.H;
+        int x0 = (((int)fx % W) + W) % W, y0 = (((int)fy % H) + H) % H;   // AddressMode::Repeat
+        int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
+        Foot f;
+        f.i00 = (uint32_t)y0 * fv.W + (uint32_t)x0; f.i10 = (uint32_t)y0 * fv.W + (uint32_t)x1;
+        f.i01 = (uint32_t)y1 * fv.W + (uint32_t)x0; f.i11 = (uint32_t)y1 * fv.W + (uint32_t)x1;
+        f.ax = x - fx; f.ay = y - fy;
+        return f;
+    }
+    FRT_HD static f3 lerp4(f3 t00, f3 t10, f3 t01, f3 t11, float ax, float ay) {
+        f3 top = t00 * (1.0f - ax) + t10 * ax;
+        f3 bot = t01 * (1.0f - ax) + t11 * ax;
+        return top * (1.0f - ay) + bot * ay;
+    }
+    FRT_HD f3 raw_at(uint32_t i) const { return xyz(unpack_rgba16f(fv.raw[i])); }
+    FRT_HD f3 albedo_at(uint32_t i) const { return xyz(unpack_rgba8(fv.galbedo[i])); }
+    FRT_HD f3 color(int nx, int ny) const {
+        const Foot f = foot(nx, ny);
+        return lerp4(raw_at(f.i00), raw_at(f.i10), raw_at(f.i01), raw_at(f.i11), f.ax, f.ay);
+    }
+    FRT_HD TapData get(int nx, int ny) const {
+        const Foot f = foot(nx, ny);
+        TapData t;
+        t.color = lerp4(raw_at(f.i00), raw_at(f.i10), raw_at(f.i01), raw_at(f.i11), f.ax, f.ay);
+        t.albedo = lerp4(albedo_at(f.i00), albedo_at(f.i10), albedo_at(f.i01), albedo_at(f.i11), f.ax, f.ay);
+        const uint32_t nidx = (uint32_t)ny * fv.W + (uint32_t)nx;
+        float4 sn = fv.gnormal[nidx];
+        t.normal = decode_octahedral_normal(sn.x, sn.y);
+        float4 sp4 = fv.gpos[nidx];
+        t.pos = mk3(sp4.x, sp4.y, sp4.z);
+        return t;
+    }
 };
 
 template <class Taps>
@@ -494,6 +544,10 @@ FRT_HD void post_pixel_t(const FrameView& fv, uint32_t px, uint32_t py, const Ta
     const float inv_gamma = (float)(1.0 / 2.2);
     fv.display[idx] = pack_rgba8(mk4(powf_(final_color.x, inv_gamma), powf_(final_color.y, inv_gamma), powf_(final_color.z, inv_gamma), 1.0f));
 }
-FRT_HD void post_pixel(const FrameView& fv, uint32_t px, uint32_t py) { GlobalTaps taps{fv}; post_pixel_t(fv, px, py, taps); }
+FRT_HD bool post_is_jittered(const FrameView& fv) { return fv.jitter_x != 0.0f || fv.jitter_y != 0.0f; }
+FRT_HD void post_pixel(const FrameView& fv, uint32_t px, uint32_t py) {
+    if (post_is_jittered(fv)) { JitterTaps taps{fv}; post_pixel_t(fv, px, py, taps); }
+    else { GlobalTaps taps{fv}; post_pixel_t(fv, px, py, taps); }
+}
 
 } // namespace frt

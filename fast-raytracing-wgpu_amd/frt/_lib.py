@@ -33,12 +33,14 @@ class CameraUniform(C.Structure):   # src/camera.rs:4-15
 class RenderOpts(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p),
                 ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("device_arena", C.c_void_p),
-                ("arena_bytes", C.c_uint64), ("flags", C.c_uint32), ("motion_halo_rows", C.c_uint32)]
+                ("arena_bytes", C.c_uint64), ("flags", C.c_uint32), ("motion_halo_rows", C.c_uint32), ("queue_capacity", C.c_uint32)]
 
 
 class Stats(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("frames", C.c_uint64),
-                ("ms_stage", C.c_double * 4), ("launches", C.c_uint64 * 4), ("rays_stage", (C.c_uint64 * 2) * 4), ("halo_overflow", C.c_uint64)]
+                ("ms_stage", C.c_double * 4), ("launches", C.c_uint64 * 4), ("rays_stage", (C.c_uint64 * 2) * 4), ("halo_overflow", C.c_uint64),
+                ("ms_merge", C.c_double), ("queue_overflow", C.c_uint64), ("queue_capacity", C.c_uint64),
+                ("speculated_frames", C.c_uint64), ("discarded_speculations", C.c_uint64)]
 
 
 assert C.sizeof(VertexAttr) == 32 and C.sizeof(Material) == 64 and C.sizeof(Light) == 64 and C.sizeof(CameraUniform) == 288
@@ -46,10 +48,12 @@ assert C.sizeof(VertexAttr) == 32 and C.sizeof(Material) == 64 and C.sizeof(Ligh
 FLAG_TIMING = 1
 FLAG_COMPACTION = 2
 FLAG_USE_STREAM = 4
-FLAG_OVERLAP_POST = 8
+FLAG_PIPELINE = 8
+FLAG_OVERLAP_POST = FLAG_PIPELINE      # round-1 name
 PHASE_GBUFFER, PHASE_TEMPORAL, PHASE_SPATIAL, PHASE_POST, PHASE_ALL = 1, 2, 4, 8, 15
-BUF_GPOS, BUF_GNORMAL, BUF_GALBEDO, BUF_GMOTION, BUF_RESERVOIR, BUF_RAW, BUF_DISPLAY, BUF_ACCUM = range(8)
-BUF_BPP = {BUF_GPOS: 16, BUF_GNORMAL: 16, BUF_GALBEDO: 4, BUF_GMOTION: 8, BUF_RESERVOIR: 32, BUF_RAW: 8, BUF_DISPLAY: 4, BUF_ACCUM: 16}
+PHASE_SPATIAL_INNER, PHASE_SPATIAL_EDGE = 16, 32
+BUF_GPOS, BUF_GNORMAL, BUF_GALBEDO, BUF_GMOTION, BUF_RESERVOIR, BUF_RAW, BUF_DISPLAY, BUF_ACCUM, BUF_CANDIDATE = range(9)
+BUF_BPP = {BUF_GPOS: 16, BUF_GNORMAL: 16, BUF_GALBEDO: 4, BUF_GMOTION: 8, BUF_RESERVOIR: 32, BUF_RAW: 8, BUF_DISPLAY: 4, BUF_ACCUM: 16, BUF_CANDIDATE: 16}
 
 # every symbol include/frt.h declares: (restype, argtypes)
 _P = C.c_void_p
@@ -90,13 +94,19 @@ SYMBOLS = {
     "frt_scene_get": (C.c_int, [_P, C.c_int, _P]),
     "frt_scene_bvh_stats": (C.c_int, [_P, _P]),
     "frt_camera_default": (None, [C.c_float, _U32, _U32, C.POINTER(CameraUniform)]),
+    "frt_camera_build_uniform": (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_float, _U32, _U32, _P, C.POINTER(CameraUniform), _P]),
+    "frt_camera_halton_jitter": (None, [_U32, _U32, _U32, C.c_float, _P]),
     "frt_renderer_arena_bytes": (C.c_uint64, [_U32, _U32]),
     "frt_renderer_create": (_P, [_P, _U32, _U32, C.POINTER(RenderOpts)]),
     "frt_renderer_destroy": (None, [_P]),
     "frt_renderer_render": (C.c_int, [_P, C.POINTER(CameraUniform)]),
     "frt_renderer_render_phases": (C.c_int, [_P, C.POINTER(CameraUniform), C.c_int]),
     "frt_renderer_end_frame": (C.c_int, [_P]),
+    "frt_renderer_set_jitter": (C.c_int, [_P, C.c_float, C.c_float]),
+    "frt_renderer_render_jittered": (C.c_int, [_P, C.POINTER(CameraUniform), C.c_float, C.c_float]),
     "frt_renderer_sync": (C.c_int, [_P]),
+    "frt_renderer_fence": (C.c_int, [_P]),
+    "frt_renderer_stream": (_P, [_P, C.c_int]),
     "frt_renderer_frame_count": (_U32, [_P]),
     "frt_renderer_reset": (C.c_int, [_P]),
     "frt_renderer_clear": (C.c_int, [_P]),

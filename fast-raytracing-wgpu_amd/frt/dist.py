@@ -1,24 +1,29 @@
-"""Image-strip partition of the frame across ranks and the per-frame halo exchange.
+"""Image-strip partition of the frame across ranks and the per-frame halo exchanges.
 
 The reference is single-GPU; this is the multi-GPU form of its render loop. The framebuffer is cut into `world`
 horizontal strips (contiguous in row-major, so strips gather in place); the scene is replicated. Stage dependencies:
   G-buffer  : pure function of the pixel            -> each rank also computes 12 halo rows itself, no exchange
-  temporal  : reads only its own pixel (static camera, restir.wgsl:846-855)
+  T-trace   : reads only its own pixel's G-buffer   -> no exchange (and it runs ahead of its frame, frt_renderer.hip)
+  T-merge   : reads its own pixel's previous spatial reservoir (static camera, restir.wgsl:846-855)
   spatial   : reads temporal reservoirs within 10 px (restir_spatial.wgsl:902-921); this build runs it on 2 extra rows
               per side so that post's +-2-row radiance reads (post.wgsl:93) stay local  -> needs 12 reservoir halo rows
   post      : reads the previous accumulation within +-1 row (post.wgsl:196-199)            -> needs 1 history halo row
-So ONE exchange per frame, between the temporal and spatial stages: 12 rows of reservoirs (32 B/px) and 1 row of the
-previous frame's accumulation (16 B/px) with each vertical neighbour. Everything else is local.
+Two exchanges per frame with each vertical neighbour, on different dependency chains:
+  "mid"  : 12 rows of temporal reservoirs (32 B/px) between T-merge and the spatial stage. This one sits on the frame-to-frame
+           chain (T-merge -> spatial -> T-merge); it is overlapped with the spatial stage's INTERIOR rows, which need nothing from a
+           neighbour (FRT_PHASE_SPATIAL_INNER), and only the edge rows wait for it.
+  "post" : 1 row of the previous frame's accumulation (16 B/px) for post. Posted at the start of the frame (its source is the previous
+           frame's post), waited for just before post: a whole frame of slack.
 
-Moving camera (StripPlan(motion_halo=K), Renderer(motion_halo=K)): the temporal stage reprojects into the PREVIOUS frame's spatial
+Moving camera (StripPlan(motion_halo=K), Renderer(motion_halo=K)): T-merge reprojects into the PREVIOUS frame's spatial
 reservoirs and G-buffer (restir.wgsl:846-900) and post fetches the previous accumulation bilinearly at the reprojected position
 (post.wgsl:187-266), both up to K rows outside the strip as long as the camera moves less than that per frame. The previous G-buffer
-is local (the G-buffer halo grows to K rows); a SECOND exchange, before the temporal stage, brings K rows of the previous spatial
-reservoirs and K + 1 rows of the previous accumulation from each neighbour ("pre" transfers; the accumulation row then leaves the
-mid-frame exchange). Reads beyond the halo are counted (stats()["halo_overflow"]); check_halo() raises on them.
+is local (the G-buffer halo grows to K rows); a "pre" exchange before T-merge brings K rows of the previous spatial reservoirs, and
+the "post" exchange grows to K + 1 rows. Reads beyond the halo are counted (stats()["halo_overflow"]); check_halo() raises on them.
 
 `exchange_halos` is transport-agnostic: it moves `rows(...)` tensors with torch.distributed point-to-point ops
-(backend "nccl" = RCCL over xGMI on the GPU node, "gloo" on CPU for tests).
+(backend "nccl" = RCCL over xGMI on the GPU node, "gloo" on CPU for tests). `render_strip_frame` is one frame of one rank:
+the phases and the exchanges in the order described above (what bench.py --gpus N and the multi-rank tests run).
 """
 import numpy as np
 
@@ -56,17 +61,18 @@ class StripPlan:
 
     def transfers(self, frame, when="mid"):
         """[(peer, buf, index, send_rows, recv_rows)] for frame `frame`.
-        when="mid": between its temporal and spatial stages (always); when="pre": before its temporal stage (moving camera only)."""
+        when="pre": before its T-merge (moving camera only); "mid": between T-merge and the spatial stage; "post": before its post stage."""
         hist = (frame - 1) % 2          # post.rs:209-224: history = the slot written by the previous frame
         if when == "pre":
             if self.motion_halo == 0 or frame == 0:
                 return []
-            return (self._pairs(BUF_RESERVOIR, 1, self.motion_halo)             # previous spatial reservoirs (reservoir_buffers[1])
-                    + self._pairs(BUF_ACCUM, hist, self.motion_halo + HALO_HISTORY))
-        out = self._pairs(BUF_RESERVOIR, 0, HALO_RESERVOIR)
-        if frame > 0 and self.motion_halo == 0:
-            out += self._pairs(BUF_ACCUM, hist, HALO_HISTORY)
-        return out
+            return self._pairs(BUF_RESERVOIR, 1, self.motion_halo)             # previous spatial reservoirs (reservoir_buffers[1])
+        if when == "post":
+            if frame == 0:
+                return []
+            return self._pairs(BUF_ACCUM, hist, (self.motion_halo + HALO_HISTORY) if self.motion_halo else HALO_HISTORY)
+        assert when == "mid"
+        return self._pairs(BUF_RESERVOIR, 0, HALO_RESERVOIR)
 
 
 class ArenaRows:
@@ -98,23 +104,78 @@ class ArenaRows:
             v.copy_(t, non_blocking=True)
 
 
-def exchange_halos(access, plan, frame, group=None, when="mid"):
-    """One batched point-to-point exchange with both vertical neighbours (torch.distributed; nccl = RCCL, or gloo).
-    when="pre" (moving camera): call before the frame's G-buffer / temporal phases; when="mid": between temporal and spatial."""
+    def edge_stream(self):
+        """The stream on which the renderer launches the edge rows of the spatial stage (frt_renderer_stream(r, 2)) as a torch stream."""
+        import torch
+        h = self.r.stream_handle(2)
+        if not h or h == self.r.stream_handle(0):
+            return torch.cuda.current_stream()
+        if getattr(self, "_edge", None) is None or self._edge_handle != h:
+            self._edge, self._edge_handle = torch.cuda.ExternalStream(h), h
+        return self._edge
+
+
+class _Exchange:
+    """A batched point-to-point exchange in flight: start() posts the sends / receives, finish() waits and lands the received rows."""
+
+    def __init__(self, access, works, recvs):
+        self.access, self.works, self.recvs = access, works, recvs
+
+    def finish(self):
+        for w in self.works:
+            w.wait()       # nccl: orders the CURRENT torch stream behind the transfer (no host wait); gloo: blocks the host
+        for buf, index, rrows, rb in self.recvs:
+            self.access.store(buf, index, *rrows, rb)
+        self.works, self.recvs = [], []
+
+
+def start_exchange(access, plan, frame, group=None, when="mid"):
+    """Post one batched exchange with both vertical neighbours (torch.distributed; nccl = RCCL, or gloo). Returns an _Exchange or None.
+    With the nccl backend the transfer is ordered behind the torch stream that is current HERE and finish() orders the stream that is
+    current THERE behind it: callers pick the streams (render_strip_frame)."""
     import torch.distributed as dist
     tr = plan.transfers(frame, when)
     if not tr:
-        return
+        return None
     ops, recvs = [], []
     for peer, buf, index, srows, rrows in tr:
         ops.append(dist.P2POp(dist.isend, access.rows(buf, index, *srows), peer, group))
         rb = access.recv_buffer(buf, index, *rrows)
         recvs.append((buf, index, rrows, rb))
         ops.append(dist.P2POp(dist.irecv, rb, peer, group))
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
-    for buf, index, rrows, rb in recvs:
-        access.store(buf, index, *rrows, rb)
+    return _Exchange(access, dist.batch_isend_irecv(ops), recvs)
+
+
+def exchange_halos(access, plan, frame, group=None, when="mid"):
+    """start_exchange + finish: the blocking form (CPU oracle strips; host-staged transports)."""
+    ex = start_exchange(access, plan, frame, group, when)
+    if ex:
+        ex.finish()
+
+
+def render_strip_frame(r, access, plan, cam, frame, frt, group=None):
+    """One frame of one rank's strip renderer `r` (frt.Renderer on torch's current stream, buffers in `access`'s arena).
+
+    Everything a transfer touches (reservoirs, accumulation) is produced on the renderer's main stream = torch's current stream, so the
+    transfers are ordered by that stream alone. The "post" rows (previous accumulation) are posted first: they have the whole frame to
+    arrive. The "mid" rows are posted behind T-merge and overlap the interior rows of the spatial stage; only its edge rows wait.
+    With a host-staged transport (gloo rehearsal, `access.staging`) start_exchange blocks in the device-to-host copy; same order."""
+    post = start_exchange(access, plan, frame, group, when="post")      # behind post(f-1)
+    pre = start_exchange(access, plan, frame, group, when="pre")        # behind spatial(f-1) (moving camera only)
+    if pre:
+        pre.finish()
+    r.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)        # T-merge(f) (G-buffer + T-trace ran ahead of the frame)
+    mid = start_exchange(access, plan, frame, group, when="mid")        # behind T-merge(f)
+    r.render_phases(cam, frt.PHASE_SPATIAL_INNER)                       # interior rows: need nothing from a neighbour
+    if mid:
+        import torch
+        with torch.cuda.stream(access.edge_stream()):
+            mid.finish()                                                # only the stream of the edge rows waits for the neighbours' reservoirs
+    r.render_phases(cam, frt.PHASE_SPATIAL_EDGE)                        # edge rows (beside the interior ones) + continuations
+    if post:
+        post.finish()
+    r.render_phases(cam, frt.PHASE_POST)
+    r.end_frame()
 
 
 def check_halo(renderer):
@@ -125,7 +186,8 @@ def check_halo(renderer):
 
 
 def exchange_halos_host(renderers, plans, frame, when="mid"):
-    """Same exchange between strip renderers living in ONE process (tests on a single GPU): rows go through host memory."""
+    """Same exchange between strip renderers living in ONE process (tests on a single GPU): rows go through host memory
+    (read_rows / write_rows wait for everything the renderers have enqueued)."""
     by_rank = {p.rank: r for r, p in zip(renderers, plans)}
     for r, p in zip(renderers, plans):
         for peer, buf, index, srows, _ in p.transfers(frame, when):

@@ -5,11 +5,12 @@ from ._lib import (lib, check, FrtError, RenderOpts, Stats, CameraUniform, BUF_B
 
 
 class Renderer:
-    def __init__(self, scene, width, height, max_depth=8, device=0, stream=None, rows=None, arena=None, arena_bytes=0, flags=0, motion_halo=0):
+    def __init__(self, scene, width, height, max_depth=8, device=0, stream=None, rows=None, arena=None, arena_bytes=0, flags=0, motion_halo=0,
+                 queue_capacity=0):
         """Renderer::new (renderer.rs:206). rows=(begin,end) restricts this renderer to an image strip; motion_halo = rows of
         previous-frame state kept valid beyond the strip for a moving camera (frt.dist.StripPlan(motion_halo=...))."""
         o = RenderOpts()
-        o.max_depth, o.device, o.flags = max_depth, device, flags
+        o.max_depth, o.device, o.flags, o.queue_capacity = max_depth, device, flags, queue_capacity
         if stream is not None:      # a caller-owned stream handle; 0 is the legacy default stream (torch's default current stream)
             o.stream = stream or None
             o.flags |= FLAG_USE_STREAM
@@ -41,8 +42,21 @@ class Renderer:
     def frame_count(self):       # renderer.rs:198
         return int(lib().frt_renderer_frame_count(self._h))
 
-    def render(self, camera_uniform):      # renderer.rs:349
-        check(lib().frt_renderer_render(self._h, C.byref(camera_uniform)))
+    def render(self, camera_uniform, jitter=None):      # renderer.rs:349 (jitter -> PostParams.jitter, :361-379)
+        if jitter is None:
+            check(lib().frt_renderer_render(self._h, C.byref(camera_uniform)))
+        else:
+            check(lib().frt_renderer_render_jittered(self._h, C.byref(camera_uniform), float(jitter[0]), float(jitter[1])))
+
+    def set_jitter(self, jitter):
+        check(lib().frt_renderer_set_jitter(self._h, float(jitter[0]), float(jitter[1])))
+
+    def fence(self):
+        """Order the renderer's stream behind its internal second stream (no host wait); call before using buffer_info pointers."""
+        check(lib().frt_renderer_fence(self._h))
+
+    def stream_handle(self, which=0):
+        return lib().frt_renderer_stream(self._h, which) or 0
 
     def render_phases(self, camera_uniform, phases=PHASE_ALL):
         check(lib().frt_renderer_render_phases(self._h, C.byref(camera_uniform), phases))
@@ -102,4 +116,6 @@ class Renderer:
         check(lib().frt_renderer_stats(self._h, C.byref(s)))
         return {"rays_closest": s.rays_closest, "rays_any": s.rays_any, "frames": s.frames,
                 "ms_stage": list(s.ms_stage), "launches": list(s.launches),
-                "rays_stage": [[int(s.rays_stage[i][0]), int(s.rays_stage[i][1])] for i in range(4)], "halo_overflow": int(s.halo_overflow)}
+                "rays_stage": [[int(s.rays_stage[i][0]), int(s.rays_stage[i][1])] for i in range(4)], "halo_overflow": int(s.halo_overflow),
+                "ms_merge": s.ms_merge, "queue_overflow": int(s.queue_overflow), "queue_capacity": int(s.queue_capacity),
+                "speculated_frames": int(s.speculated_frames), "discarded_speculations": int(s.discarded_speculations)}

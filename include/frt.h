@@ -142,6 +142,15 @@ int frt_scene_bvh_stats(const frt_scene* s, uint32_t stats[4]);
 
 /* ---- camera: src/camera.rs:207-256 build_uniform at the initial pose (:40-42), jitter 0 (:202-203) ------------ */
 void frt_camera_default(float aspect, uint32_t frame_count, uint32_t num_lights, frt_camera_uniform* out);
+/* CameraController::build_uniform, src/camera.rs:207-256, for any pose (position, yaw, pitch: the controller's state, :38-56), jitter
+ * (the projection shear of :224-228; NULL = (0, 0)) and previous view-projection (NULL = the controller's initial IDENTITY, i.e. the
+ * first frame, :233-238). unjittered_view_proj (16 floats, may be NULL) is the second element of the returned tuple, which the caller
+ * keeps as the next frame's prev_view_proj (state.rs:172). */
+int frt_camera_build_uniform(const float position[3], float yaw, float pitch, const float* prev_view_proj_colmajor, float aspect,
+                             uint32_t frame_count, uint32_t num_lights, const float jitter[2], frt_camera_uniform* out, float* unjittered_view_proj);
+/* CameraController::get_halton_jitter, src/camera.rs:182-205. `scale` stands for the literal 0 the reference multiplies the Halton
+ * offsets by (:202-203): 0 reproduces the shipped reference (no jitter), 1 gives the sequence its comments describe. */
+void frt_camera_halton_jitter(uint32_t index, uint32_t width, uint32_t height, float scale, float out[2]);
 
 /* ---- renderer: src/renderer.rs ---------------------------------------------------------------------------- */
 typedef struct frt_render_opts {
@@ -157,17 +166,28 @@ typedef struct frt_render_opts {
                                  accumulation: frt/dist.py exchanges them before the temporal stage) so that temporal reprojection and the
                                  history fetch of a MOVING camera may land there; the G-buffer halo grows to cover them. 0 = static camera.
                                  Reads that fall outside are counted in frt_stats.halo_overflow (the frame then differs from a 1-GPU frame). */
+    uint32_t queue_capacity;  /* slots of each continuation queue (paths parked between two launches of a traced stage); 0 -> sized from the
+                                 share of paths that reach the first cut and grown by frt_renderer_stats after an overflow. Any value is
+                                 safe: a path that finds its queue full is finished in place (frt_stats.queue_overflow counts them). */
 } frt_render_opts;
 #define FRT_FLAG_TIMING 1u          /* record per-stage HIP events every frame (frt_stats.ms_*) */
-#define FRT_FLAG_OVERLAP_POST 8u    /* side-stream schedule: the stages that hang off the temporal -> spatial -> temporal chain (the next frame's
-                                       G-buffer, this frame's post) run beside the latency-bound continuation launches on a second stream; post(f)
-                                       is then enqueued behind the temporal pixel kernel of frame f+1, or at the next sync / read / reset
-                                       (DESIGN.md section 6). Same pixels; reads and frt_renderer_sync see completed frames as without the flag. */
+#define FRT_FLAG_PIPELINE 8u        /* two-stream schedule: the G-buffer and the T-trace half of the temporal stage of the NEXT
+                                       frame run on a second stream beside this frame's spatial continuation launches and post (the latency-bound
+                                       part of the frame). The next frame's camera is speculated (this camera, frame_count + 1, prev_view_proj =
+                                       view_proj: a camera that did not move) and checked against the real uniform at the next render call; a wrong
+                                       guess is dropped and redone in order. Same pixels; reads, frt_renderer_sync and frt_renderer_stats see
+                                       completed frames as without the flag. Callers that read the G-buffer / motion targets through
+                                       frt_renderer_buffer_info on their own stream call frt_renderer_fence first. */
+#define FRT_FLAG_OVERLAP_POST FRT_FLAG_PIPELINE   /* round-1 name */
 #define FRT_FLAG_USE_STREAM 4u      /* opts->stream is authoritative even when NULL (= the legacy default stream, e.g. torch's current stream) */
 #define FRT_FLAG_COMPACTION 2u      /* temporal / spatial stages through the workgroup-compacting kernels (opt-in: measured slower than
                                        one thread per pixel on the Cornell Box, profiles/r1_v3_*; same pixels either way) */
 
-enum { FRT_PHASE_GBUFFER = 1, FRT_PHASE_TEMPORAL = 2, FRT_PHASE_SPATIAL = 4, FRT_PHASE_POST = 8, FRT_PHASE_ALL = 15 };
+/* FRT_PHASE_SPATIAL = the whole spatial stage. A strip renderer may issue it in two parts so that the halo exchange overlaps with
+ * work: FRT_PHASE_SPATIAL_INNER (rows whose 10-row reuse neighbourhood lies inside the strip: needs nothing from a neighbour),
+ * then, once the neighbours' temporal reservoirs have arrived, FRT_PHASE_SPATIAL_EDGE (the remaining rows + the continuations). */
+enum { FRT_PHASE_GBUFFER = 1, FRT_PHASE_TEMPORAL = 2, FRT_PHASE_SPATIAL = 4, FRT_PHASE_POST = 8, FRT_PHASE_ALL = 15,
+       FRT_PHASE_SPATIAL_INNER = 16, FRT_PHASE_SPATIAL_EDGE = 32 };
 
 /* Per-pixel buffers (RenderTargets, src/renderer.rs:26-170; reservoirs src/passes/restir.rs:329-348) */
 enum {
@@ -179,7 +199,9 @@ enum {
     FRT_BUF_RESERVOIR = 4,   /* 32 B/px, [0] temporal result, [1] spatial result */
     FRT_BUF_RAW = 5,         /* rgba16f  8 B/px */
     FRT_BUF_DISPLAY = 6,     /* rgba8    4 B/px */
-    FRT_BUF_ACCUM = 7        /* vec4f    16 B/px, x2 */
+    FRT_BUF_ACCUM = 7,       /* vec4f    16 B/px, x2 */
+    FRT_BUF_CANDIDATE = 8    /* vec4f    16 B/px: (v1_pos, p_hat) of the temporal stage's fresh candidate path, T-trace -> T-merge (no reference
+                                counterpart: restir.wgsl keeps it in registers between :825 and :826) */
 };
 
 typedef struct frt_stats {
@@ -190,6 +212,11 @@ typedef struct frt_stats {
     uint64_t launches[4];     /* launches per stage */
     uint64_t rays_stage[4][2];/* per stage {closest, any}; post issues none */
     uint64_t halo_overflow;   /* strips: previous-frame reads (reprojection, history) outside own rows +- motion_halo_rows; 0 for a whole frame */
+    double ms_merge;          /* summed T-merge kernel time (ms_stage[1] is T-trace); FRT_FLAG_TIMING only */
+    uint64_t queue_overflow;  /* paths that found their continuation queue full and were finished in place */
+    uint64_t queue_capacity;  /* current slots per continuation queue */
+    uint64_t speculated_frames;       /* FRT_FLAG_PIPELINE: frames whose G-buffer + T-trace ran ahead and were adopted */
+    uint64_t discarded_speculations;  /* ... and speculated work that did not match the next camera and was dropped */
 } frt_stats;
 
 uint64_t frt_renderer_arena_bytes(uint32_t width, uint32_t height);
@@ -201,7 +228,21 @@ int frt_renderer_render(frt_renderer* r, const frt_camera_uniform* cam);
 /* Strip form: enqueue only `phases` (multi-GPU: a halo exchange sits between TEMPORAL and SPATIAL); frt_renderer_end_frame advances frame_count. */
 int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, int phases);
 int frt_renderer_end_frame(frt_renderer* r);
+/* PostParams.jitter (renderer.rs:14, :361-379): render(..., jitter) writes it before the post pass. set_jitter applies to the post
+ * stages enqueued after it; render_jittered = set_jitter + render. (0, 0) — the shipped reference, camera.rs:202-203 — is the default.
+ * Non-zero jitter makes post take bilinear radiance / albedo taps (post.wgsl:72-78, :97-109, :152-158); whole-frame renderers only. */
+int frt_renderer_set_jitter(frt_renderer* r, float jitter_x, float jitter_y);
+int frt_renderer_render_jittered(frt_renderer* r, const frt_camera_uniform* cam, float jitter_x, float jitter_y);
 int frt_renderer_sync(frt_renderer* r);                       /* block until enqueued work is done */
+/* Stream-level fence, no host wait: the renderer's stream (opts->stream) is ordered behind everything the renderer has enqueued on
+ * its internal second stream (FRT_FLAG_PIPELINE). Call before touching buffers from frt_renderer_buffer_info on the caller's stream
+ * (halo exchange, zero-copy views). */
+int frt_renderer_fence(frt_renderer* r);
+/* The streams the renderer enqueues on: which = 0 the main stream (opts->stream: T-merge, spatial, post — everything a halo exchange
+ * reads), 1 the second stream of FRT_FLAG_PIPELINE (G-buffer + T-trace of the next frame), 2 the stream on which a strip renderer
+ * under FRT_FLAG_PIPELINE launches FRT_PHASE_SPATIAL_EDGE's pixel kernels: a caller that receives halo rows orders THAT stream behind
+ * the transfer before it issues the phase (frt/dist.py). Both equal stream 0 without the flag. */
+void* frt_renderer_stream(const frt_renderer* r, int which);
 uint32_t frt_renderer_frame_count(const frt_renderer* r);     /* renderer.frame_count, :198 */
 int frt_renderer_reset(frt_renderer* r);                      /* frame_count = 0 only, as state.rs:152 / renderer.rs:346 (buffers keep their contents) */
 int frt_renderer_clear(frt_renderer* r);                      /* back to the state right after create: zeroed targets, frame_count = 0, stats = 0 */

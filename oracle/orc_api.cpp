@@ -104,6 +104,12 @@ void orc_camera_default(float aspect, uint32_t frame, uint32_t nlights, void* ou
     CameraUniform c = camera_default(aspect, frame, nlights); memcpy(out288, &c, 288);
 }
 
+void orc_camera_build(const float pos[3], float yaw, float pitch, const float* prev_vp, float aspect, uint32_t frame, uint32_t nlights,
+                      float jx, float jy, void* out288, float* unjittered16) {
+    CameraUniform c = camera_build(V3(pos[0], pos[1], pos[2]), yaw, pitch, prev_vp, aspect, frame, nlights, jx, jy, unjittered16); memcpy(out288, &c, 288);
+}
+void orc_camera_halton_jitter(uint32_t index, uint32_t w, uint32_t h, float scale, float out[2]) { camera_halton_jitter(index, w, h, scale, out); }
+
 // ---- tracing probes (T2): closest/any over n rays; o,d are n*3 floats
 void orc_trace_closest(void* sp, int use_bvh, uint32_t n, const float* o, const float* d, float tmin, float tmax,
                        float* t_out, uint32_t* tri_out, float* uv_out, uint8_t* front_out, uint64_t stats[4]) {
@@ -132,6 +138,7 @@ void orc_renderer_render_phases(void* r, const void* cam288, int phases, uint32_
     CameraUniform c; memcpy(&c, cam288, 288); ((Renderer*)r)->render_phases(c, phases, y0, y1);
 }
 void orc_renderer_end_frame(void* r) { ((Renderer*)r)->end_frame(); }
+void orc_renderer_set_jitter(void* r, float jx, float jy) { ((Renderer*)r)->jitter[0] = jx; ((Renderer*)r)->jitter[1] = jy; }
 uint32_t orc_renderer_frame_count(void* r) { return ((Renderer*)r)->frame_count; }
 // Buffers. which: 0 gpos[i] (16 B/px), 1 gnormal[i] (16), 2 galbedo[i] (4), 3 gmotion (8), 4 reservoirs[i] (32),
 // 5 raw rgba16f (8), 6 display rgba8 (4), 7 accum[i] (16)

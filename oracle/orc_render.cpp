@@ -785,16 +785,46 @@ static vec3 ycocg_to_rgb(vec3 c) { float y = c.x, co = c.y, cg = c.z; return V3(
 static vec3 resolve_tonemap(vec3 c) { return c / (1.0f + fmax_(c.x, fmax_(c.y, c.z))); }
 static vec3 resolve_inverse_tonemap(vec3 c) { return c / (1.0f - fmax_(c.x, fmax_(c.y, c.z))); }
 
+// textureSampleLevel(raw_tex | albedo_tex, smp, uv + unjitter_offset, 0).rgb of post.wgsl:72-78, :97-109, :152-158 at the sample
+// point of pixel (nx, ny). Sampler of renderer.rs:240-249: Linear, Repeat. jitter == (0, 0) (the shipped reference, camera.rs:202-203):
+// the sample point is the texel centre, the sample is that texel (contract: DESIGN.md §3). Otherwise an f32 bilinear blend of the four
+// texels around it, in the order written here, wrapping at the image border.
+struct PostSampler {
+    const Renderer& R; uint32_t cur; bool jittered; vec2 unjitter_offset;
+    PostSampler(const Renderer& r, uint32_t cur_) : R(r), cur(cur_) {
+        jittered = R.jitter[0] != 0.0f || R.jitter[1] != 0.0f;
+        unjitter_offset = V2(-R.jitter[0], R.jitter[1]) * 0.5f;   // post.wgsl:73
+    }
+    vec3 raw_texel(int x, int y) const { return xyz(unpack_rgba16f(R.raw[(uint32_t)y * R.W + (uint32_t)x])); }
+    vec3 albedo_texel(int x, int y) const { return xyz(unpack_rgba8(R.galbedo[cur][(uint32_t)y * R.W + (uint32_t)x])); }
+    template <class Texel> vec3 sample(int nx, int ny, Texel texel) const {
+        if (!jittered) return texel(nx, ny);
+        int W = (int)R.W, H = (int)R.H;
+        vec2 size = V2((float)R.W, (float)R.H);
+        vec2 uv = (V2((float)nx, (float)ny) + V2(0.5f, 0.5f)) / size;
+        vec2 sample_uv = uv + unjitter_offset;
+        float x = sample_uv.x * size.x - 0.5f, y = sample_uv.y * size.y - 0.5f;
+        float fx = floorf(x), fy = floorf(y);
+        float ax = x - fx, ay = y - fy;
+        int x0 = ((int)fx % W + W) % W, y0 = ((int)fy % H + H) % H;
+        int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
+        vec3 top = texel(x0, y0) * (1.0f - ax) + texel(x1, y0) * ax;
+        vec3 bot = texel(x0, y1) * (1.0f - ax) + texel(x1, y1) * ax;
+        return top * (1.0f - ay) + bot * ay;
+    }
+    vec3 color(int nx, int ny) const { return sample(nx, ny, [this](int x, int y) { return raw_texel(x, y); }); }
+    vec3 albedo(int nx, int ny) const { return sample(nx, ny, [this](int x, int y) { return albedo_texel(x, y); }); }
+};
+
 static void post_pixel(Ctx& c, Renderer& R, uint32_t px, uint32_t py) {
-    // jitter == 0 (camera.rs:202-203): every textureSampleLevel(raw_tex / albedo_tex) lands on a texel centre,
-    // restated as a texel fetch (post row).
     uint32_t cur = c.cur;
     const std::vector<vec4>& history = R.accum[cur ^ 1u];   // post.rs:209-224
     std::vector<vec4>& accumulation = R.accum[cur];
     int W = (int)R.W, H = (int)R.H;
     uint32_t idx = py * R.W + px;
-    vec3 center_color = xyz(unpack_rgba16f(R.raw[idx]));
-    vec3 center_albedo = xyz(unpack_rgba8(R.galbedo[cur][idx]));
+    const PostSampler smp(R, cur);
+    vec3 center_color = smp.color((int)px, (int)py);
+    vec3 center_albedo = smp.albedo((int)px, (int)py);
     vec4 cn = R.gnormal[cur][idx];
     vec3 center_normal = decode_octahedral_normal(V2(cn.x, cn.y));
     vec3 center_pos = xyz(R.gpos[cur][idx]);
@@ -807,8 +837,8 @@ static void post_pixel(Ctx& c, Renderer& R, uint32_t px, uint32_t py) {
             int nx = (int)px + dx, ny = (int)py + dy;
             if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
             uint32_t nidx = (uint32_t)ny * R.W + (uint32_t)nx;
-            vec3 sample_color = xyz(unpack_rgba16f(R.raw[nidx]));
-            vec3 sample_albedo = xyz(unpack_rgba8(R.galbedo[cur][nidx]));
+            vec3 sample_color = smp.color(nx, ny);
+            vec3 sample_albedo = smp.albedo(nx, ny);
             vec4 sn = R.gnormal[cur][nidx];
             vec3 sample_normal = decode_octahedral_normal(V2(sn.x, sn.y));
             vec3 sample_pos = xyz(R.gpos[cur][nidx]);
@@ -834,7 +864,7 @@ static void post_pixel(Ctx& c, Renderer& R, uint32_t px, uint32_t py) {
         for (int dx = -1; dx <= 1; dx++) {
             int nx = (int)px + dx, ny = (int)py + dy;
             vec3 s_col;
-            if (nx >= 0 && ny >= 0 && nx < W && ny < H) s_col = xyz(unpack_rgba16f(R.raw[(uint32_t)ny * R.W + (uint32_t)nx]));
+            if (nx >= 0 && ny >= 0 && nx < W && ny < H) s_col = smp.color(nx, ny);
             else s_col = filtered_color;
             vec3 s_ycocg = rgb_to_ycocg(resolve_tonemap(s_col));
             m1 += s_ycocg;

@@ -19,6 +19,7 @@ struct Renderer {
     bool use_bvh;
     int nthreads;
     uint32_t frame_count = 0;
+    float jitter[2] = {0.0f, 0.0f};          // PostParams.jitter (renderer.rs:14, :376): what render(..., jitter) writes before the post pass
 
     // RenderTargets (src/renderer.rs:26-170); textures/buffers start zeroed like wgpu resources
     std::vector<vec4> gpos[2], gnormal[2];

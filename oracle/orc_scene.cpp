@@ -3,6 +3,7 @@
 // (Cargo.lock:876) matrix helpers those files call (glam is not vendored in /root/reference; its
 // published scalar algorithms are restated here).
 #include "orc_scene.hpp"
+#include <cstring>
 #include <map>
 #include <array>
 #include <utility>
@@ -426,11 +427,9 @@ void create_restir_scene(Scene& b) {   // scenes.rs:133-223
 }
 
 // ---------------------------------------------------------------- src/camera.rs
-CameraUniform camera_default(float aspect, uint32_t frame_count, uint32_t num_lights) {
-    // camera.rs:40-42 pose; :207-256 build_uniform with jitter == (0,0) (camera.rs:202-203) and
-    // prev_view_proj == IDENTITY -> unjittered view_proj (static camera: same every frame, state.rs:172)
-    vec3 position = V3(0.0f, 0.0f, 3.0f);
-    float yaw = -90.0f * (3.14159265358979323846f / 180.0f), pitch = 0.0f;
+// camera.rs:207-256 build_uniform for any controller state. prev_view_proj == nullptr: the initial IDENTITY (first frame, :233-238).
+CameraUniform camera_build(vec3 position, float yaw, float pitch, const float* prev_view_proj, float aspect, uint32_t frame_count,
+                           uint32_t num_lights, float jitter_x, float jitter_y, float* unjittered_out) {
     float sy = sinf(yaw), cy = cosf(yaw), sp = sinf(pitch), cp = cosf(pitch);
     vec3 forward = glam_normalize(V3(cp * cy, sp, cp * sy));
     // look_at_rh(eye, eye + forward, Y) = look_to_rh(eye, (eye + forward) - eye, Y)
@@ -445,18 +444,41 @@ CameraUniform camera_default(float aspect, uint32_t frame_count, uint32_t num_li
     float fov = 45.0f * (3.14159265358979323846f / 180.0f);
     float sf = sinf(0.5f * fov), cf = cosf(0.5f * fov);
     float h = cf / sf, w = h / aspect, r = 100.0f / (0.1f - 100.0f);
-    mat4 proj;
-    proj.c[0] = V4(w, 0, 0, 0); proj.c[1] = V4(0, h, 0, 0); proj.c[2] = V4(0, 0, r, -1); proj.c[3] = V4(0, 0, r * 0.1f, 0);
+    mat4 proj_base;
+    proj_base.c[0] = V4(w, 0, 0, 0); proj_base.c[1] = V4(0, h, 0, 0); proj_base.c[2] = V4(0, 0, r, -1); proj_base.c[3] = V4(0, 0, r * 0.1f, 0);
+    mat4 vp_unjittered = mul(proj_base, view);
+    mat4 proj = proj_base;
+    proj.c[2].x += jitter_x;   // camera.rs:226
+    proj.c[2].y += jitter_y;   // camera.rs:227
     mat4 vp = mul(proj, view);
     mat4 vi = mat4_inverse(view), pi = mat4_inverse(proj);
     CameraUniform cu{};
     auto store = [](float* dst, const mat4& m) {
         for (int c = 0; c < 4; ++c) { dst[4 * c] = m.c[c].x; dst[4 * c + 1] = m.c[c].y; dst[4 * c + 2] = m.c[c].z; dst[4 * c + 3] = m.c[c].w; }
     };
-    store(cu.view_proj, vp); store(cu.view_inverse, vi); store(cu.proj_inverse, pi); store(cu.prev_view_proj, vp);
+    store(cu.view_proj, vp); store(cu.view_inverse, vi); store(cu.proj_inverse, pi);
+    if (prev_view_proj) memcpy(cu.prev_view_proj, prev_view_proj, 64); else store(cu.prev_view_proj, vp_unjittered);
     cu.view_pos[0] = position.x; cu.view_pos[1] = position.y; cu.view_pos[2] = position.z; cu.view_pos[3] = 1.0f;
     cu.frame_count = frame_count; cu.num_lights = num_lights;
+    if (unjittered_out) store(unjittered_out, vp_unjittered);
     return cu;
+}
+// camera.rs:182-205; `scale` = the literal 0 of :202-203
+void camera_halton_jitter(uint32_t index, uint32_t width, uint32_t height, float scale, float out[2]) {
+    auto halton = [](uint32_t i, uint32_t base) {
+        float f = 1.0f, r = 0.0f;
+        while (i > 0) { f = f / (float)base; r = r + f * (float)(i % base); i = i / base; }
+        return r;
+    };
+    float halton_x = halton(index + 1u, 2u) - 0.5f;
+    float halton_y = halton(index + 1u, 3u) - 0.5f;
+    out[0] = (halton_x * scale) / (float)width;
+    out[1] = (halton_y * scale) / (float)height;
+}
+CameraUniform camera_default(float aspect, uint32_t frame_count, uint32_t num_lights) {
+    // camera.rs:40-42 pose; :207-256 build_uniform with jitter == (0,0) (camera.rs:202-203) and
+    // prev_view_proj == IDENTITY -> unjittered view_proj (static camera: same every frame, state.rs:172)
+    return camera_build(V3(0.0f, 0.0f, 3.0f), -90.0f * (3.14159265358979323846f / 180.0f), 0.0f, nullptr, aspect, frame_count, num_lights, 0.0f, 0.0f, nullptr);
 }
 
 } // namespace orc

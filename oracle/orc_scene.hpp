@@ -130,5 +130,9 @@ void create_restir_scene(Scene& s);
 
 // src/camera.rs:38-56, :207-256 with the fixed initial pose and zero jitter (camera.rs:202-203)
 CameraUniform camera_default(float aspect, uint32_t frame_count, uint32_t num_lights);
+// src/camera.rs:207-256 for any controller state / jitter / previous view-projection, and :182-205 (scale = the literal 0 of :202-203)
+CameraUniform camera_build(vec3 position, float yaw, float pitch, const float* prev_view_proj, float aspect, uint32_t frame_count,
+                           uint32_t num_lights, float jitter_x, float jitter_y, float* unjittered_out);
+void camera_halton_jitter(uint32_t index, uint32_t width, uint32_t height, float scale, float out[2]);
 
 } // namespace orc

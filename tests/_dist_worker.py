@@ -66,8 +66,9 @@ def main():
             exchange_halos(acc, plan, f, when="pre")
             r.render_phases(cams[f], 1, max(rb - hg, 0) if a.world > 1 else 0, min(re + hg, H) if a.world > 1 else H)
             r.render_phases(cams[f], 2, rb, re)
-            exchange_halos(acc, plan, f)
+            exchange_halos(acc, plan, f, when="mid")
             r.render_phases(cams[f], 4, max(rb - 2, 0), min(re + 2, H))
+            exchange_halos(acc, plan, f, when="post")
             r.render_phases(cams[f], 8, rb, re)
             r.end_frame()
         mine = torch.from_numpy(r.read_rows(7, (N - 1) % 2, rb, re).copy())
@@ -81,12 +82,9 @@ def main():
         r = frt.Renderer(fs, W, H, rows=(rb, re), arena=arena.data_ptr() + off, arena_bytes=nbytes,
                          stream=torch.cuda.current_stream().cuda_stream, motion_halo=K, flags=a.flags)
         acc = ArenaRows(r, arena, staging_device="cpu")
+        from frt.dist import render_strip_frame
         for f in range(N):
-            exchange_halos(acc, plan, f, when="pre")
-            r.render_phases(cams[f], frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
-            exchange_halos(acc, plan, f)
-            r.render_phases(cams[f], frt.PHASE_SPATIAL | frt.PHASE_POST)
-            r.end_frame()
+            render_strip_frame(r, acc, plan, cams[f], f, frt)      # the loop bench.py --gpus N runs (host-staged transport here)
         torch.cuda.synchronize()
         mine = torch.from_numpy(r.read_rows(7, (N - 1) % 2, rb, re).copy())
         st = r.stats(); rays = st["rays_closest"] + st["rays_any"]

@@ -14,6 +14,7 @@ class HostCheck:
         L.hc_render.argtypes = [P, P, C.c_int]
         L.hc_read.restype = C.c_int; L.hc_read.argtypes = [P, C.c_int, C.c_int, P]
         L.hc_rays.argtypes = [P, P]
+        L.hc_set_jitter.argtypes = [P, C.c_float, C.c_float]
         L.hc_trace.argtypes = [P, C.c_int, U32, P, P, C.c_float, P, P, P, P, P]
 
     def renderer(self, scene, w, h, max_depth=8, nthreads=8, state_machine=False):
@@ -40,6 +41,9 @@ class HcRenderer:
     def render(self, cam):
         cam = np.ascontiguousarray(np.frombuffer(bytes(cam), np.uint8))
         self.L.hc_render(self.h, cam.ctypes.data, self.sm)
+
+    def set_jitter(self, jitter):
+        self.L.hc_set_jitter(self.h, float(jitter[0]), float(jitter[1]))
 
     def read(self, buf, index=0):
         out = np.zeros((self.hgt, self.w, BPP[buf]), np.uint8)

@@ -23,6 +23,8 @@ class Oracle:
             "orc_scene_add_texture": (C.c_int, [P, C.c_int, P]), "orc_scene_build": (C.c_int, [P]),
             "orc_scene_counts": (None, [P, P]), "orc_scene_get": (None, [P, C.c_int, P]),
             "orc_scene_set_bvh": (C.c_int, [P, P, U32, P, U32]), "orc_camera_default": (None, [C.c_float, U32, U32, P]),
+            "orc_camera_build": (None, [P, C.c_float, C.c_float, P, C.c_float, U32, U32, C.c_float, C.c_float, P, P]),
+            "orc_camera_halton_jitter": (None, [U32, U32, U32, C.c_float, P]), "orc_renderer_set_jitter": (None, [P, C.c_float, C.c_float]),
             "orc_trace_closest": (None, [P, C.c_int, U32, P, P, C.c_float, C.c_float, P, P, P, P, P]),
             "orc_trace_any": (None, [P, C.c_int, U32, P, P, C.c_float, P, P]),
             "orc_renderer_create": (P, [P, U32, U32, U32, C.c_int, C.c_int]), "orc_renderer_destroy": (None, [P]),
@@ -47,6 +49,20 @@ class Oracle:
         buf = np.zeros(288, np.uint8)
         self.L.orc_camera_default(aspect, frame, nlights, buf.ctypes.data)
         return buf
+
+    def camera_build(self, position, yaw, pitch, prev_view_proj, aspect, frame, nlights, jitter=(0.0, 0.0)):
+        """camera.rs:207-256 -> (288 uniform bytes, unjittered view_proj as 16 f32). prev_view_proj=None: first frame (IDENTITY)."""
+        buf = np.zeros(288, np.uint8); unj = np.zeros(16, np.float32)
+        pos = np.ascontiguousarray(position, np.float32)
+        prev = None if prev_view_proj is None else np.ascontiguousarray(prev_view_proj, np.float32)
+        self.L.orc_camera_build(pos.ctypes.data, yaw, pitch, None if prev is None else prev.ctypes.data, aspect, frame, nlights,
+                                jitter[0], jitter[1], buf.ctypes.data, unj.ctypes.data)
+        return buf, unj
+
+    def halton_jitter(self, index, width, height, scale=0.0):
+        out = np.zeros(2, np.float32)
+        self.L.orc_camera_halton_jitter(index, width, height, scale, out.ctypes.data)
+        return float(out[0]), float(out[1])
 
     def mesh(self, which, subdiv=0):
         c = (C.c_uint32 * 2)()
@@ -123,6 +139,9 @@ class OrcRenderer:
 
     def end_frame(self):
         self.L.orc_renderer_end_frame(self.h)
+
+    def set_jitter(self, jitter):      # PostParams.jitter, renderer.rs:376
+        self.L.orc_renderer_set_jitter(self.h, float(jitter[0]), float(jitter[1]))
 
     @property
     def frame_count(self):

@@ -19,6 +19,8 @@ struct HostCheck {
     std::vector<float4> gpos[2], gnormal[2], accum[2];
     std::vector<uint32_t> galbedo[2], display;
     std::vector<float2> gmotion;
+    std::vector<float4> cand;
+    float jitter[2] = {0.0f, 0.0f};
     std::vector<ReservoirView> res[2];
     std::vector<uint2> raw;
     unsigned long long rays[2] = {0, 0};
@@ -28,12 +30,20 @@ struct HostCheck {
 
 // One stage through the cut / park / resume protocol of the continuation kernels, sequentially: every pixel runs head + bounces
 // [1, cut), survivors are parked in a host-side ContQueue, then each parked path is resumed for [cut, cut2) and [cut2, max).
+// split (stage 1 only): the form the default kernels run — T-trace ends with the candidate record, a separate T-merge pass follows.
 template <int STAGE>
-static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned long long rc[2], bool pair = false) {
+static void finish_on_host(PathCtx& c, const FrameView& fv, uint32_t pix, const ReservoirView& r, const LoopState& s, bool split) {
+    if (STAGE == 1) {
+        if (split) fv.cand[pix] = temporal_candidate(s.accumulated, s.v1_pos);
+        else { PathState st; make_path_state(st, pix, s.accumulated, s.v1_pos); temporal_finalize(c, st); }
+    } else spatial_tail(c, pix, r, s.accumulated, s.v1_pos);
+}
+template <int STAGE>
+static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned long long rc[2], bool split) {
     const uint32_t npix = h->W * h->H;
     std::vector<uint32_t> wa((size_t)kContWordsSpatial * npix), wb((size_t)kContWordsSpatial * npix);
     uint32_t ca = 0, cb = 0;
-    ContQueue qa{wa.data(), &ca, npix}, qb{wb.data(), &cb, npix};
+    ContQueue qa{wa.data(), &ca, npix, nullptr}, qb{wb.data(), &cb, npix, nullptr};
     uint32_t stack[kStackDepth];
     constexpr int V = STAGE == 1 ? 0 : 1;
     for (uint32_t pix = 0; pix < npix; ++pix) {
@@ -41,7 +51,7 @@ static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned lo
         ReservoirView r = zero_reservoir();
         uint32_t seed;
         if (STAGE == 1) {
-            if (fv.gpos[pix].w < 0.0f) { fv.res_temporal[pix] = zero_reservoir(); continue; }
+            if (fv.gpos[pix].w < 0.0f) { if (!split) fv.res_temporal[pix] = zero_reservoir(); continue; }
             seed = temporal_seed(fv, pix);
         } else {
             if (!spatial_neighbors(c, pix, r)) { rc[1] += c.n_any; continue; }
@@ -52,31 +62,10 @@ static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned lo
         if (s.alive) path_loop<V>(c, s, 1u, cut < fv.max_depth ? cut : fv.max_depth);
         rc[0] += c.n_closest; rc[1] += c.n_any;
         if (s.alive) cont_store(qa, ca++, pix, c.rng, true, s, STAGE == 2 ? &r : nullptr);
-        else if (STAGE == 1) { PathState st; make_path_state(st, pix, s.accumulated, s.v1_pos); temporal_finalize(c, st); }
-        else spatial_tail(c, pix, r, s.accumulated, s.v1_pos);
+        else finish_on_host<STAGE>(c, fv, pix, r, s, split);
     }
     uint32_t d0 = cut;
     ContQueue* qin = &qa; ContQueue* qout = &qb;
-    if (pair) {   // the two-wave tail (walker + lighter, frt_mono.hpp), one path at a time: phase 1, exchange, phase 2, estimate
-        for (uint32_t slot = 0; slot < *qin->count; ++slot) {
-            PathCtx c(h->sv, fv, stack, 1u), cl(h->sv, fv, stack, 1u);
-            LoopState s; ReservoirView r = zero_reservoir(); uint32_t pix; bool owned;
-            cont_load(*qin, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
-            Walker w; walker_init(w, s);
-            f3 contribution = splat3(0.0f);
-            for (uint32_t depth = d0;; ++depth) {
-                NeeJob job;
-                bool issued = walker_trace<V>(c, w, depth, job);
-                bool fin = walker_shade<V>(c, w, depth, contribution, issued);   // consumes the PREVIOUS level's estimate
-                if (issued) contribution = lighter_estimate<V>(cl, job);
-                if (fin) break;
-            }
-            rc[0] += c.n_closest; rc[1] += cl.n_any;
-            if (STAGE == 1) { PathState st; make_path_state(st, pix, w.s.accumulated, w.s.v1_pos); temporal_finalize(c, st); }
-            else spatial_tail(c, pix, r, w.s.accumulated, w.s.v1_pos);
-        }
-        return;
-    }
     while (*qin->count > 0) {
         uint32_t d1 = d0 + 2u < fv.max_depth ? d0 + 2u : fv.max_depth;
         *qout->count = 0;
@@ -87,12 +76,13 @@ static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned lo
             path_loop<V>(c, s, d0, d1);
             rc[0] += c.n_closest; rc[1] += c.n_any;
             if (s.alive) { cont_store(*qout, (*qout->count)++, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr); }
-            else if (STAGE == 1) { PathState st; make_path_state(st, pix, s.accumulated, s.v1_pos); temporal_finalize(c, st); }
-            else spatial_tail(c, pix, r, s.accumulated, s.v1_pos);
+            else finish_on_host<STAGE>(c, fv, pix, r, s, split);
         }
         std::swap(qin, qout);
         d0 = d1;
     }
+    if (STAGE == 1 && split)
+        for (uint32_t pix = 0; pix < npix; ++pix) temporal_merge_pixel(h->sv, fv, pix);
 }
 
 extern "C" {
@@ -122,13 +112,16 @@ void* hc_create(const frt_scene* s, uint32_t W, uint32_t H, uint32_t max_depth, 
         h->galbedo[i].assign(n, 0u); h->res[i].assign(n, zero_reservoir());
     }
     h->display.assign(n, 0u); h->gmotion.assign(n, make_float2(0, 0)); h->raw.assign(n, make_uint2(0, 0));
+    h->cand.assign(n, make_float4(0, 0, 0, 0));
     return h;
 }
 void hc_destroy(void* p) { delete (HostCheck*)p; }
 
+void hc_set_jitter(void* p, float jx, float jy) { HostCheck* h = (HostCheck*)p; h->jitter[0] = jx; h->jitter[1] = jy; }
+
 // sm == 1: drive the resumable state machine (frt_path.hpp) instead of the straight-line functions (frt_mono.hpp);
 // sm >= 2: straight-line functions cut at bounce depth `sm` with the continuation-queue protocol (run_stage_cut);
-// sm >= 100: cut at sm - 100, then the two-wave tail (walker / lighter) runs every parked path to its end
+// sm >= 1000: cut at sm - 1000 AND the temporal stage split into T-trace (candidate record) + T-merge, as the default kernels run it
 void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     HostCheck* h = (HostCheck*)p;
     uint32_t cur = h->frame_count & 1u, prv = cur ^ 1u;
@@ -136,6 +129,7 @@ void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     fv.gpos = h->gpos[cur].data(); fv.gnormal = h->gnormal[cur].data(); fv.galbedo = h->galbedo[cur].data();
     fv.gpos_prev = h->gpos[prv].data(); fv.gnormal_prev = h->gnormal[prv].data(); fv.galbedo_prev = h->galbedo[prv].data();
     fv.gmotion = h->gmotion.data(); fv.res_temporal = h->res[0].data(); fv.res_spatial = h->res[1].data();
+    fv.cand = h->cand.data(); fv.jitter_x = h->jitter[0]; fv.jitter_y = h->jitter[1];
     fv.raw = h->raw.data(); fv.display = h->display.data(); fv.history = h->accum[prv].data(); fv.accum = h->accum[cur].data();
     fv.ray_counters = nullptr; fv.W = h->W; fv.H = h->H; fv.frame_count = h->frame_count; fv.max_depth = h->max_depth;
     fv.y0 = 0; fv.y1 = h->H; fv.own_y0 = 0; fv.own_y1 = h->H; fv.prev_y0 = 0; fv.prev_y1 = h->H; fv.overflow = nullptr;
@@ -145,8 +139,8 @@ void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     for (int stage = 0; stage < 4; ++stage) {
         if (sm >= 2 && (stage == 1 || stage == 2)) {
             unsigned long long r2[2] = {0, 0};
-            const bool pair = sm >= 100; const uint32_t cutd = (uint32_t)(pair ? sm - 100 : sm);
-            if (stage == 1) run_stage_cut<1>(h, fv, cutd, r2, pair); else run_stage_cut<2>(h, fv, cutd, r2, pair);
+            const bool split = sm >= 1000; const uint32_t cutd = (uint32_t)(split ? sm - 1000 : sm);
+            if (stage == 1) run_stage_cut<1>(h, fv, cutd, r2, split); else run_stage_cut<2>(h, fv, cutd, r2, false);
             h->rays[0] += r2[0]; h->rays[1] += r2[1];
             continue;
         }

@@ -54,20 +54,25 @@ def test_strip_plan_geometry(frt):
     assert all(p.row_end - p.row_begin == 135 for p in plans)
     # every send has a matching receive of the same rows on the peer
     for f in (0, 3):
-        sends = {(p.rank, peer, buf, idx, s) for p in plans for peer, buf, idx, s, r in p.transfers(f)}
-        recvs = {(peer, p.rank, buf, idx, r) for p in plans for peer, buf, idx, s, r in p.transfers(f)}
-        assert sends == recvs
-    assert len(plans[0].transfers(0)) == 1 and len(plans[3].transfers(2)) == 4
+        for when in ("mid", "post"):
+            sends = {(p.rank, peer, buf, idx, s) for p in plans for peer, buf, idx, s, r in p.transfers(f, when)}
+            recvs = {(peer, p.rank, buf, idx, r) for p in plans for peer, buf, idx, s, r in p.transfers(f, when)}
+            assert sends == recvs
+    # "mid": 12 rows of temporal reservoirs per neighbour, every frame; "post": 1 row of the previous accumulation, from frame 1 on
+    assert len(plans[0].transfers(0)) == 1 and len(plans[3].transfers(2)) == 2
+    assert plans[3].transfers(0, "post") == [] and len(plans[3].transfers(2, "post")) == 2 and plans[3].transfers(2, "pre") == []
+    assert {(buf, idx, s[1] - s[0]) for _, buf, idx, s, _ in plans[3].transfers(2, "post")} == {(7, 1, 1)}
     with pytest.raises(ValueError):
         StripPlan(64, 8, 0)
-    # moving camera: a second exchange before the temporal stage; the accumulation rows move there
+    # moving camera: a "pre" exchange of the previous spatial reservoirs before T-merge; the accumulation rows grow to K + 1
     mp = [StripPlan(1080, 8, k, motion_halo=16) for k in range(8)]
-    assert mp[2].transfers(0, "pre") == [] and len(mp[2].transfers(3, "pre")) == 4 and len(mp[2].transfers(3)) == 2
-    for when in ("pre", "mid"):
+    assert mp[2].transfers(0, "pre") == [] and len(mp[2].transfers(3, "pre")) == 2 and len(mp[2].transfers(3)) == 2
+    for when in ("pre", "mid", "post"):
         sends = {(q.rank, peer, buf, idx, s) for q in mp for peer, buf, idx, s, r in q.transfers(3, when)}
         recvs = {(peer, q.rank, buf, idx, r) for q in mp for peer, buf, idx, s, r in q.transfers(3, when)}
         assert sends == recvs
-    assert {(buf, idx, s[1] - s[0]) for _, buf, idx, s, _ in mp[2].transfers(3, "pre")} == {(4, 1, 16), (7, 0, 17)}
+    assert {(buf, idx, s[1] - s[0]) for _, buf, idx, s, _ in mp[2].transfers(3, "pre")} == {(4, 1, 16)}
+    assert {(buf, idx, s[1] - s[0]) for _, buf, idx, s, _ in mp[2].transfers(3, "post")} == {(7, 0, 17)}
     with pytest.raises(ValueError):
         StripPlan(1080, 8, 0, motion_halo=200)
     # unequal (work-balanced) strips

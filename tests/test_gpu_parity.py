@@ -11,6 +11,19 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4    # per-pixel L_inf on the accumulation buffer (north_star)
 
 
+def _strip_frame(frt, strips, plans, cam, f):
+    """One frame of several strip renderers living in this process, rows exchanged through the host: the three exchanges of
+    frt/dist.py in their places, the spatial stage issued as interior rows, then edge rows (the overlap form bench.py uses)."""
+    from frt.dist import exchange_halos_host
+    exchange_halos_host(strips, plans, f, when="pre")
+    for s in strips: s.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
+    for s in strips: s.render_phases(cam, frt.PHASE_SPATIAL_INNER)
+    exchange_halos_host(strips, plans, f, when="mid")
+    for s in strips: s.render_phases(cam, frt.PHASE_SPATIAL_EDGE)
+    exchange_halos_host(strips, plans, f, when="post")
+    for s in strips: s.render_phases(cam, frt.PHASE_POST); s.end_frame()
+
+
 @pytest.fixture(scope="module")
 def gpu(frt):
     if frt.lib().frt_device_count() < 1:
@@ -110,11 +123,7 @@ def test_strips_equal_whole_image(gpu):
     for f in range(N):
         cam = frt.CameraController().build_uniform(W / H, f, 2)
         whole.render(cam)
-        for s in strips:
-            s.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
-        exchange_halos_host(strips, plans, f)
-        for s in strips:
-            s.render_phases(cam, frt.PHASE_SPATIAL | frt.PHASE_POST); s.end_frame()
+        _strip_frame(frt, strips, plans, cam, f)
     want = whole.read_accum(); wd = whole.read_display()
     for s, p in zip(strips, plans):
         got = s.read_accum()
@@ -211,12 +220,8 @@ def test_post_overlap_flag_gives_identical_frames(gpu, orc):
     strips = [frt.Renderer(fs, W, H, rows=(p.row_begin, p.row_end), flags=frt.FLAG_OVERLAP_POST) for p in plans]
     for f in range(N):
         cam = frt.CameraController().build_uniform(W / H, f, 2)
-        ro.render(cam); r.render(cam)                      # no sync between frames: post(f) really overlaps frame f+1
-        for s in strips:
-            s.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
-        exchange_halos_host(strips, plans, f)
-        for s in strips:
-            s.render_phases(cam, frt.PHASE_SPATIAL | frt.PHASE_POST); s.end_frame()
+        ro.render(cam); r.render(cam)                      # no sync between frames: frame f+1's G-buffer + T-trace really run beside spatial(f)
+        _strip_frame(frt, strips, plans, cam, f)
     last = (N - 1) % 2
     for b, idx in ((0, last), (1, last), (2, last), (4, 0), (4, 1), (5, 0), (6, 0), (7, last), (7, last ^ 1)):
         assert r.read_buffer(b, idx).tobytes() == ro.read(b, idx).tobytes(), (b, idx)
@@ -226,16 +231,12 @@ def test_post_overlap_flag_gives_identical_frames(gpu, orc):
         assert s.read_buffer(7, last)[p.row_begin:p.row_end].tobytes() == want[p.row_begin:p.row_end].tobytes()
 
 
-@pytest.mark.parametrize("cuts", ["0", "3", "2,3,5,6", "1,2,3,4", "5,7", "pair:3", "pair:3,4", "pair:1", "pair:2,6"])
+@pytest.mark.parametrize("cuts", ["0", "3", "2,3,5,6", "1,2,3,4", "5,7", "1", "2,6", "abc", "3;5"])
 def test_every_cut_configuration_is_bit_identical(gpu, orc, monkeypatch, cuts):
     """The continuation-queue protocol (pixel kernel -> park after the roulette -> continue kernels, one counter per segment) must
     not depend on where or how often paths are cut. FRT_CUTS is the experiment knob frt_renderer_create reads."""
     frt = gpu
-    if cuts.startswith("pair:"):       # the last segment through the two-wave kernel (walker + lighter)
-        monkeypatch.setenv("FRT_PAIR", "1"); cuts = cuts[5:]
-    else:
-        monkeypatch.setenv("FRT_PAIR", "0")
-    monkeypatch.setenv("FRT_CUTS", cuts)
+    monkeypatch.setenv("FRT_CUTS", cuts)      # ("abc", "3;5": malformed lists must neither hang the parser nor change pixels)
     W, H, depth = 160, 96, 8
     fs = frt.scenes.create_cornell_box()
     os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
@@ -265,10 +266,7 @@ def test_moving_camera_strips_equal_whole_image(gpu):
         plans = [StripPlan(H, 3, k, motion_halo=halo) for k in range(3)]
         strips = [frt.Renderer(fs, W, H, rows=(p.row_begin, p.row_end), motion_halo=halo, flags=flags) for p in plans]
         for f, cam in enumerate(cams):
-            exchange_halos_host(strips, plans, f, when="pre")
-            for s in strips: s.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
-            exchange_halos_host(strips, plans, f)
-            for s in strips: s.render_phases(cam, frt.PHASE_SPATIAL | frt.PHASE_POST); s.end_frame()
+            _strip_frame(frt, strips, plans, cam, f)
         same = all(np.array_equal(s.read_accum()[p.row_begin:p.row_end], want[p.row_begin:p.row_end]) and
                    np.array_equal(s.read_display()[p.row_begin:p.row_end], wd[p.row_begin:p.row_end]) for s, p in zip(strips, plans))
         if halo:
@@ -320,9 +318,85 @@ def test_config2_4k_eight_strips_equal_whole(gpu):
     assert all(p.row_end - p.row_begin == 270 for p in plans)
     strips = [frt.Renderer(fs, W, H, rows=(p.row_begin, p.row_end)) for p in plans]
     for f, cam in enumerate(cams):
-        for s in strips: s.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
-        exchange_halos_host(strips, plans, f)
-        for s in strips: s.render_phases(cam, frt.PHASE_SPATIAL | frt.PHASE_POST); s.end_frame()
+        _strip_frame(frt, strips, plans, cam, f)
     for s, p in zip(strips, plans):
         assert np.array_equal(s.read_rows(frt.BUF_ACCUM, (N - 1) % 2, p.row_begin, p.row_end).view(np.float32).reshape(-1, W, 4), want[p.row_begin:p.row_end])
     assert sum(s.stats()["rays_closest"] + s.stats()["rays_any"] for s in strips) == total
+
+
+def test_pipeline_speculation_is_adopted_for_a_static_camera_and_dropped_for_a_moving_one(gpu, orc):
+    """FRT_FLAG_PIPELINE: G-buffer + T-trace of frame f+1 run ahead under a speculated camera. Static camera: adopted from the third
+    frame on (one frame to see the camera, one to see that it did not move), every buffer and the ray counts identical to the oracle.
+    Moving camera: never speculated (nothing to drop). A camera that stops / starts moving: wrong guesses are dropped, same pixels."""
+    frt = gpu
+    import _scenes
+    W, H, N = 160, 96, 7
+    fs = frt.scenes.create_cornell_box()
+    os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    r = frt.Renderer(fs, W, H, flags=frt.FLAG_PIPELINE); ro = os_.renderer(W, H, 8, True, 16)
+    for f in range(N):
+        cam = frt.CameraController().build_uniform(W / H, f, 2)
+        r.render(cam); ro.render(cam)
+    compare_all(r.read_buffer, ro.read, N - 1, "pipeline, static camera")
+    st, so = r.stats(), ro.stats()["total"]
+    assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
+    assert st["speculated_frames"] == N - 2 and st["discarded_speculations"] == 0, st
+    # static -> moving -> static: the guess made during the last static frame is wrong and must be dropped
+    r = frt.Renderer(fs, W, H, flags=frt.FLAG_PIPELINE); ro = os_.renderer(W, H, 8, True, 16)
+    moving = _scenes.moving_camera_uniforms(frt, W / H, 2, 12)
+    seq = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(4)] + moving[4:8]
+    still = moving[7]
+    for f in range(8, 12):
+        c = frt.CameraUniform.from_buffer_copy(bytes(still)); c.frame_count = f; c.prev_view_proj[:] = list(still.view_proj); seq.append(c)
+    for f, cam in enumerate(seq):
+        r.render(cam); ro.render(cam)
+        if f in (3, 4, 5, 8, 11):
+            compare_all(r.read_buffer, ro.read, f, "pipeline, camera starts and stops moving")
+    st, so = r.stats(), ro.stats()["total"]
+    assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
+    assert st["discarded_speculations"] == 1 and st["speculated_frames"] >= 3, st
+
+
+def test_queue_overflow_finishes_paths_in_place(gpu, orc):
+    """A continuation queue far too small for the paths that reach the cut: the overflowing lanes keep their paths and finish them in
+    place — same pixels, same ray counts — and the overflow is counted; a renderer with the default capacity grows it after an overflow."""
+    frt = gpu
+    W, H = 160, 96
+    fs = frt.scenes.create_cornell_box()
+    os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    for flags in (0, frt.FLAG_PIPELINE):
+        ro = os_.renderer(W, H, 8, True, 16)
+        os.environ["FRT_CUTS"] = "2,4"       # (a small image would run uncut by default)
+        try:
+            r = frt.Renderer(fs, W, H, flags=flags, queue_capacity=100)
+        finally:
+            os.environ.pop("FRT_CUTS")
+        for f in range(4):
+            cam = frt.CameraController().build_uniform(W / H, f, 2)
+            r.render(cam); ro.render(cam)
+            compare_all(r.read_buffer, ro.read, f, f"queue capacity 100, flags {flags}")
+        st, so = r.stats(), ro.stats()["total"]
+        assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
+        assert st["queue_overflow"] > 1000 and st["queue_capacity"] == 100, st
+
+
+def test_jittered_frames_on_gpu(gpu, orc):
+    """SURVEY §8f-2 jitter: frt_renderer_render_jittered with non-zero Halton jitter (projection shear + bilinear post taps) against
+    the oracle, every buffer of every frame."""
+    frt = gpu
+    W, H = 160, 96
+    fs = frt.scenes.create_cornell_box()
+    os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    for flags, scale in ((0, 1.0), (frt.FLAG_PIPELINE, 23.0)):
+        r = frt.Renderer(fs, W, H, flags=flags); ro = os_.renderer(W, H, 8, True, 16)
+        ctl = frt.CameraController()
+        for f in range(4):
+            jit = ctl.get_halton_jitter(f, W, H, scale)
+            cam = ctl.build_uniform(W / H, f, 2, jit); ctl.commit_frame()
+            ro.set_jitter(jit); ro.render(cam)
+            r.render(cam, jitter=jit)
+            compare_all(r.read_buffer, ro.read, f, f"jitter x{scale}, flags {flags}")
+    strip = frt.Renderer(fs, W, H, rows=(0, 48))
+    strip.set_jitter((0.01, 0.0))
+    with pytest.raises(frt.FrtError):
+        strip.render(frt.CameraController().build_uniform(W / H, 0, 2))

@@ -19,7 +19,7 @@ def compare_all(got_reader, want_reader, frame, ctx=""):
                 raise AssertionError(f"{ctx} frame {frame} {NAMES[b]}[{idx}]: {len(d)} pixels differ, first at {tuple(d[0])}")
 
 
-@pytest.mark.parametrize("sm", [0, 1, 2, 3, 5, 101, 103, 104], ids=["straight", "state_machine", "cut2", "cut3", "cut5", "pair1", "pair3", "pair4"])
+@pytest.mark.parametrize("sm", [0, 1, 2, 3, 5, 1001, 1003, 1008], ids=["straight", "state_machine", "cut2", "cut3", "cut5", "split_cut1", "split_cut3", "split_uncut"])
 @pytest.mark.parametrize("which,size,depth,frames,bvh", [("cornell", 64, 8, 4, True), ("cornell", 128, 1, 2, False),
                                                          ("cornell", 48, 16, 2, True), ("restir", 48, 8, 3, True)])
 def test_stage_functions_match_oracle(frt, orc, hostcheck, which, size, depth, frames, bvh, sm):
@@ -54,3 +54,31 @@ def test_moving_camera_matches_oracle(frt, orc, hostcheck):
     assert np.abs(mot).max() > 1e-3                       # the motion path really is exercised
     res_t = ro.read(4, 0).view(np.uint32)
     assert (res_t[..., 2] > 1).any()                      # and temporal reuse still merges some reprojected reservoirs
+
+
+@pytest.mark.parametrize("scale", [1.0, 23.0], ids=["halton", "beyond_a_pixel"])
+def test_jittered_frames_match_oracle(frt, orc, hostcheck, scale):
+    """SURVEY §8f-2 jitter plumbing: Halton jitter (camera.rs:182-205 with the literal 0 of :202-203 replaced by `scale`) shears the
+    projection (camera.rs:224-228) and reaches post as PostParams.jitter (renderer.rs:361-379), where the radiance / albedo taps
+    become bilinear samples at uv + unjitter_offset (post.wgsl:72-78, :97-109, :152-158). scale 23: offsets beyond a pixel, so the
+    Repeat addressing at the image border is exercised too."""
+    fs = frt.scenes.create_cornell_box(); os_ = orc.cornell()
+    os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    W, H = 80, 56
+    ro = os_.renderer(W, H, 8, True, 8); rh = hostcheck.renderer(fs, W, H, 8, 8)
+    ctl = frt.CameraController()
+    plain = None
+    for f in range(4):
+        jit = ctl.get_halton_jitter(f, W, H, scale)
+        assert jit == orc.halton_jitter(f, W, H, scale) and jit != (0.0, 0.0)
+        cam = ctl.build_uniform(W / H, f, 2, jit); ctl.commit_frame()
+        ro.set_jitter(jit); rh.set_jitter(jit)
+        ro.render(cam); rh.render(cam)
+        compare_all(rh.read, ro.read, f, f"jitter x{scale}")
+    # and it is not a no-op: the same frames without PostParams.jitter accumulate to a different image
+    ro2 = os_.renderer(W, H, 8, True, 8); ctl2 = frt.CameraController()
+    for f in range(4):
+        cam = ctl2.build_uniform(W / H, f, 2, ctl2.get_halton_jitter(f, W, H, scale)); ctl2.commit_frame()
+        ro2.render(cam)
+    assert ro2.read(7, 1).tobytes() != ro.read(7, 1).tobytes()
+    assert ctl.get_halton_jitter(3, W, H) == (0.0, 0.0) or ctl.get_halton_jitter(3, W, H) == (-0.0, 0.0)     # the shipped reference: x 0

@@ -99,3 +99,28 @@ def test_bvh_is_valid(frt):
                     assert np.all(f[c, 0:3] >= bmin) and np.all(f[c, 4:7] <= bmax)
                     stack.append((c, d + 1))
         assert np.all(seen == 1) and maxd == st["depth"]
+
+
+def test_camera_build_uniform_matches_oracle(frt, orc):
+    """camera.rs:207-256 for arbitrary controller states, jitter (projection shear, :224-228) and previous view-projection
+    (:233-238), and get_halton_jitter (:182-205): product host code vs the oracle's separate restatement, bit for bit."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    for k in range(40):
+        pos = rng.uniform(-2, 2, 3).astype(np.float32); yaw = float(np.float32(rng.uniform(-3.2, 3.2))); pitch = float(np.float32(rng.uniform(-1.5, 1.5)))
+        aspect = float(np.float32(rng.uniform(0.5, 2.5))); W, H = int(rng.integers(16, 4000)), int(rng.integers(16, 2200))
+        jit = frt.CameraController.get_halton_jitter(k, W, H, 1.0 if k % 3 else 0.0)
+        assert jit == orc.halton_jitter(k, W, H, 1.0 if k % 3 else 0.0)
+        ctl = frt.CameraController(pos, yaw, pitch)
+        prev = None
+        for f in range(3):
+            cu = ctl.build_uniform(aspect, f, 2, jit)
+            want, unj = orc.camera_build(pos, yaw, pitch, prev, aspect, f, 2, jit)
+            assert bytes(cu) == want.tobytes() and np.array_equal(np.asarray(ctl.unjittered_view_proj, np.float32), unj)
+            ctl.commit_frame(); prev = unj           # state.rs:172
+            ctl.position[0] += 0.05; pos = np.asarray(ctl.position, np.float32)
+    # the default pose is the reference's initial controller state (camera.rs:40-42)
+    assert bytes(frt.CameraController().build_uniform(16 / 9, 5, 2)) == orc.camera(16 / 9, 5, 2).tobytes()
+    # jitter shears exactly two entries of the projection: view_proj changes, view_inverse does not
+    a = frt.CameraController().build_uniform(1.5, 0, 2); b = frt.CameraController().build_uniform(1.5, 0, 2, (0.01, -0.02))
+    assert list(a.view_inverse) == list(b.view_inverse) and list(a.view_proj) != list(b.view_proj) and list(a.prev_view_proj) == list(b.prev_view_proj)

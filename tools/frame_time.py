@@ -11,7 +11,8 @@ import frt
 W, H = 1920, 1080
 scene = frt.scenes.create_cornell_box()
 cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(72)]
-r = frt.Renderer(scene, W, H, flags=frt.FLAG_TIMING | frt.FLAG_OVERLAP_POST)
+flags = int(os.environ.get('FRT_FLAGS', frt.FLAG_TIMING | frt.FLAG_PIPELINE))      # experiment knob: e.g. FRT_FLAGS=1 = timing only, one stream
+r = frt.Renderer(scene, W, H, flags=flags)
 best = None
 for rnd in range(3):
     r.clear()
@@ -22,4 +23,6 @@ for rnd in range(3):
     ms = [(a - b) / 64 for a, b in zip(s1["ms_stage"], s0["ms_stage"])]
     t = (t1 - t0) / 64 * 1e3
     if best is None or t < best[0]: best = (t, ms)
-print(f"{sys.argv[1] if len(sys.argv) > 1 else 'default'} FRT_CUTS={os.environ.get('FRT_CUTS', '-')} {best[0]:.3f} ms/frame stages " + " ".join(f"{m:.3f}" for m in best[1]), flush=True)
+st = r.stats()
+print(f"speculated {st['speculated_frames']} discarded {st['discarded_speculations']} overflow {st['queue_overflow']} cap {st['queue_capacity']} merge_ms {st['ms_merge'] / max(st['frames'], 1):.4f}")
+print(f"{sys.argv[1] if len(sys.argv) > 1 else 'default'} flags={flags} FRT_CUTS={os.environ.get('FRT_CUTS', '-')} {best[0]:.3f} ms/frame stages " + " ".join(f"{m:.3f}" for m in best[1]), flush=True)

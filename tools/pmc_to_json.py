@@ -1,0 +1,61 @@
+"""Turn the rocprofv3 --pmc passes of tools/profile_all.sh (gpurun_out/pmc_<tag>_*) and the VALU calibration (gpurun_out/valu_calib.txt)
+into the JSON bench.py reads for its roofline block: per-kernel per-launch means, HBM bytes and VALU wave-instructions per frame, the
+calibrated issue cost, and the hash of the kernel sources they were measured on (bench.py withholds the numbers when the hash differs).
+Run HERE (the repository with .git), after the gpurun call that produced the passes:
+    python tools/pmc_to_json.py r2 > profiles/r2_pmc.json"""
+import collections, csv, glob, json, os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import source_hash     # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "run"
+tab = collections.defaultdict(dict)
+launches = {}
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            if "frt::" in k:
+                name = k.replace("frt::", "").split("(")[0].replace("void ", "")
+                for c, x in v.items():
+                    tab[name][c] = sum(x) / len(x)
+                    launches[name] = len(x)
+frames = max(launches.values()) if launches else 0       # every kernel is launched once per frame (or not at all)
+kern = {}
+for k, v in tab.items():
+    e = dict(v)
+    e["launches_per_frame"] = launches[k] / frames if frames else 0
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        e["hbm_bytes"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024       # gfx950: FETCH_SIZE counts 2 x 32 B units per KiB reported (MI355X_MICROARCH.md §HBM)
+    if "SQ_THREAD_CYCLES_VALU" in v and v.get("SQ_ACTIVE_INST_VALU"):
+        e["lane_utilisation"] = v["SQ_THREAD_CYCLES_VALU"] / (64 * v["SQ_ACTIVE_INST_VALU"])
+    if "SQ_WAIT_ANY" in v and v.get("SQ_WAVE_CYCLES"):
+        e["wait_frac"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
+    kern[k] = e
+calib = {}
+try:
+    for line in open(os.path.join(ROOT, "gpurun_out", "valu_calib.txt")):
+        m = re.search(r"(independent|dependent)\s+K=(\d).*shader clock ([\d.]+) GHz.*a wave needs ([\d.]+) cycles.*-> ([\d.]+) SIMD cycles", line)
+        if m:
+            calib[f"{m.group(1)}_K{m.group(2)}"] = {"shader_clock_ghz": float(m.group(3)), "own_cycles_per_inst": float(m.group(4)), "simd_cycles_per_wave_inst": float(m.group(5))}
+except OSError:
+    pass
+sat = calib.get("independent_K8") or calib.get("independent_K4") or {"simd_cycles_per_wave_inst": 2.0, "shader_clock_ghz": 2.4}
+out = {
+    "source_hash": source_hash(),
+    "git_head": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
+    "workload": "bench.py --cpu-frames 0 --steps 16 --warmup 4 (1920x1080, two-stream schedule), per-launch means",
+    "kernels": kern,
+    "hbm_bytes_per_frame": sum(e.get("hbm_bytes", 0) * e["launches_per_frame"] for e in kern.values()),
+    "valu_insts_per_frame": sum(e.get("SQ_INSTS_VALU", 0) * e["launches_per_frame"] for e in kern.values()),
+    "lane_utilisation": {k: round(e["lane_utilisation"], 3) for k, e in kern.items() if "lane_utilisation" in e},
+    "cycles_per_valu_inst": sat["simd_cycles_per_wave_inst"],     # saturated SIMD (8 independent waves): the issue cost of one wave-instruction
+    "shader_clock_ghz": sat["shader_clock_ghz"],
+    "simds": 1024,
+    "calibration": calib,
+}
+print(json.dumps(out, indent=1))
