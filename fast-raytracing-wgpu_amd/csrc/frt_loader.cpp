@@ -732,13 +732,18 @@ uint32_t pack16(uint32_t cur, uint32_t val, bool high) {   // material.rs:77-84
     return high ? ((cur & 0x0000FFFFu) | (v << 16)) : ((cur & 0xFFFF0000u) | v);
 }
 // texture index -> image index (texture.source().index(), loader.rs:75-92)
-bool texture_source(const Doc& d, const JVal* info, uint32_t& image_index) {
+bool texture_source(const Doc& d, const JVal* info, uint32_t& image_index, std::vector<std::string>* warnings) {
     if (!info || info->type != JVal::Obj) return false;
     long long ti = info->integer("index", -1);
     const auto& tex = d.root.arr("textures");
     if (ti < 0 || (size_t)ti >= tex.size()) return false;
     long long src = tex[(size_t)ti].integer("source", -1);
     if (src < 0) return false;
+    // the gltf crate rejects a document whose texture names an image that does not exist; here the slot is left empty (0xFFFF) with a warning
+    if ((size_t)src >= d.root.arr("images").size()) {
+        if (warnings) warnings->push_back("texture " + std::to_string(ti) + " refers to image " + std::to_string(src) + ", which does not exist: texture slot left empty");
+        return false;
+    }
     image_index = (uint32_t)src;
     return true;
 }
@@ -804,11 +809,11 @@ bool load_gltf(const std::string& path, LoadedModel& out, std::string& err) {
         m.tex_info_1 = pack16(pack16(m.tex_info_1, 0xFFFFFFFFu, false), 0xFFFFFFFFu, true);
         m.tex_info_2 = pack16(m.tex_info_2, 0xFFFFFFFFu, false);
         uint32_t ii;
-        if (texture_source(d, pbr.get("baseColorTexture"), ii)) m.tex_info_0 = pack16(m.tex_info_0, ii, false);
-        if (texture_source(d, jm.get("normalTexture"), ii)) m.tex_info_0 = pack16(m.tex_info_0, ii, true);
-        if (texture_source(d, jm.get("occlusionTexture"), ii)) m.tex_info_1 = pack16(m.tex_info_1, ii, false);
-        if (texture_source(d, jm.get("emissiveTexture"), ii)) m.tex_info_1 = pack16(m.tex_info_1, ii, true);
-        if (texture_source(d, pbr.get("metallicRoughnessTexture"), ii)) m.tex_info_2 = pack16(m.tex_info_2, ii, false);
+        if (texture_source(d, pbr.get("baseColorTexture"), ii, &out.warnings)) m.tex_info_0 = pack16(m.tex_info_0, ii, false);
+        if (texture_source(d, jm.get("normalTexture"), ii, &out.warnings)) m.tex_info_0 = pack16(m.tex_info_0, ii, true);
+        if (texture_source(d, jm.get("occlusionTexture"), ii, &out.warnings)) m.tex_info_1 = pack16(m.tex_info_1, ii, false);
+        if (texture_source(d, jm.get("emissiveTexture"), ii, &out.warnings)) m.tex_info_1 = pack16(m.tex_info_1, ii, true);
+        if (texture_source(d, pbr.get("metallicRoughnessTexture"), ii, &out.warnings)) m.tex_info_2 = pack16(m.tex_info_2, ii, false);
         const auto& je = jm.arr("emissiveFactor");
         for (size_t k = 0; k < 3; ++k) m.emissive_factor[k] = (k < je.size() && je[k].is_num()) ? (float)je[k].n : 0.0f;
         out.materials.push_back(m);

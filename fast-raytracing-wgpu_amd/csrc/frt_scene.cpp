@@ -318,6 +318,21 @@ void SceneBuilder::flatten() {
 
 void SceneBuilder::build() {
     error.clear();
+    // Texture layers and light indices reach the kernels unchecked (sample_layer: base + layer * 4 MiB): validate them here, once.
+    // wgpu would reject an out-of-range layer at bind time / clamp the fetch; here it would be an out-of-bounds read on the GPU.
+    for (size_t i = 0; i < materials.size() && error.empty(); ++i) {
+        const frt_material& m = materials[i];
+        const struct { uint32_t id; size_t layers; const char* what; } slots[5] = {
+            {m.tex_info_0 & 0xFFFFu, color_textures.size(), "base colour"}, {m.tex_info_0 >> 16, data_textures.size(), "normal"},
+            {m.tex_info_1 & 0xFFFFu, data_textures.size(), "occlusion"}, {m.tex_info_1 >> 16, color_textures.size(), "emissive"},
+            {m.tex_info_2 & 0xFFFFu, data_textures.size(), "metallic-roughness"}};
+        for (const auto& t : slots)
+            if (t.id != 0xFFFFu && t.id >= t.layers)
+                error = "material " + std::to_string(i) + ": " + t.what + " texture layer " + std::to_string(t.id) + " does not exist (" + std::to_string(t.layers) + " layers)";
+        if (m.light_index >= 0 && (size_t)m.light_index >= lights.size())
+            error = "material " + std::to_string(i) + ": light_index " + std::to_string(m.light_index) + " does not exist (" + std::to_string(lights.size()) + " lights)";
+    }
+    if (!error.empty()) { built = false; return; }
     flatten();
     build_bvh2();
     build_gpu_layout();

@@ -380,3 +380,34 @@ def test_gltf_showcase_scenes(frt, tmp_path):
     assert [l.type_ for l in lights] == [1, 1, 1] and list(lights[0].position) == [8.0, 4.0, 2.0] and lights[0].emission[3] == 80.0
     fb = frt.scenes.create_chocolate_truffle_scene(tmp_path / "missing.glb", fallback=path)   # falls back to the avocado scene
     assert fb.counts()["lights"] == 1
+
+
+def test_out_of_range_texture_and_light_indices_never_reach_the_gpu(frt, tmp_path):
+    """A texture whose `source` names an image that does not exist (the gltf crate rejects such a document) leaves the slot empty and
+    is reported; a material whose texture layer or light index does not exist makes SceneBuilder.build() fail instead of becoming an
+    out-of-bounds read in sample_layer."""
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    w = _gltf.GltfWriter()
+    w.primitive(0, {"POSITION": w.accessor(tri)}, indices=w.accessor(np.array([0, 1, 2], np.uint16)), material=0)
+    p = tmp_path / "badtex.gltf"; w.save_gltf(str(p), embed=True)
+    j = json.loads(p.read_text())
+    j["textures"] = [{"source": 9999}]
+    j["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}, "normalTexture": {"index": 0}}]
+    p.write_text(json.dumps(j))
+    m = frt.loader.load_gltf(p)
+    assert _mat_tex(m.material(0)) == (None, None, None, None, None)
+    assert any("9999" in x and "does not exist" in x for x in m.warnings())
+    # builder level: a hand-made material with a layer / light that does not exist
+    for field, value, text in (("tex_info_0", 57, "base colour texture layer 57"), ("tex_info_2", 0xFFFF0000 | 9, "metallic-roughness texture layer 9"),
+                               ("light_index", 3, "light_index 3")):
+        b = frt.SceneBuilder()
+        mesh = b.add_mesh(frt.geometry.create_plane())
+        mat = frt.material_new((1, 1, 1, 1))
+        if field == "tex_info_0":
+            mat.tex_info_0 = 0xFFFF0000 | value
+        else:
+            setattr(mat, field, value)
+        b.add_instance(mesh, b.add_material(mat), np.eye(4, dtype=np.float32))
+        with pytest.raises(frt.FrtError) as e:
+            b.build()
+        assert text in str(e.value), str(e.value)
