@@ -143,6 +143,42 @@ void SceneBuilder::build_bvh2() {
     if ((int)bvh_depth > kMaxBvhDepth) error = "BVH depth exceeds the traversal stack";
 }
 
+// Quantized form of the pair nodes (frt_trace.hpp: QBvh): child boxes on a 16-bit grid over the box of all (padded) node boxes, rounded
+// outward by one extra quantum, which covers the rounding of the grid-space slab test on the device (its error is a few ulp of a
+// coordinate, a quantum is 2^-16 of the scene extent). Absent children get an inverted box.
+static void quantize_pair_nodes(SceneBuilder& b) {
+    const size_t n = b.pair_nodes.size();
+    b.qnode_a.assign(n * 4, 0u); b.qnode_b.assign(n * 4, 0u);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (const PairNode& p : b.pair_nodes)
+        for (int c = 0; c < 2; ++c) {
+            uint32_t ref; memcpy(&ref, &p.q[12 + c], 4);
+            if (ref == kNoChild) continue;
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)p.q[6 * c + a]); hi[a] = std::max(hi[a], (double)p.q[6 * c + 3 + a]); }
+        }
+    for (int a = 0; a < 3; ++a) {
+        if (!(hi[a] > lo[a])) { hi[a] = lo[a] + 1e-3; }
+        const double ext = hi[a] - lo[a];
+        b.qmin[a] = (float)(lo[a] - 1e-6 * ext);
+        b.qstep[a] = (float)((ext * (1.0 + 4e-6)) / 65531.0);      // leaves room for the outward quanta at both ends
+    }
+    auto q_lo = [&](double v, int a) { double g = std::floor((v - (double)b.qmin[a]) / (double)b.qstep[a]) - 1.0; return (uint32_t)std::min(65535.0, std::max(0.0, g)); };
+    auto q_hi = [&](double v, int a) { double g = std::ceil((v - (double)b.qmin[a]) / (double)b.qstep[a]) + 1.0; return (uint32_t)std::min(65535.0, std::max(0.0, g)); };
+    for (size_t i = 0; i < n; ++i) {
+        const PairNode& p = b.pair_nodes[i];
+        for (int c = 0; c < 2; ++c) {
+            uint32_t ref; memcpy(&ref, &p.q[12 + c], 4);
+            uint32_t l[3], h[3];
+            for (int a = 0; a < 3; ++a) {
+                if (ref == kNoChild) { l[a] = 65535u; h[a] = 0u; }
+                else { l[a] = q_lo(p.q[6 * c + a], a); h[a] = q_hi(p.q[6 * c + 3 + a], a); }
+            }
+            uint32_t* w = (c == 0 ? b.qnode_a.data() : b.qnode_b.data()) + 4 * i;
+            w[0] = l[0] | (l[1] << 16); w[1] = l[2] | (h[0] << 16); w[2] = h[1] | (h[2] << 16); w[3] = ref;
+        }
+    }
+}
+
 void SceneBuilder::build_gpu_layout() {
     pair_nodes.clear(); tri_slots.clear(); instances_dev.clear(); shade_tris.clear();
     if (!error.empty()) return;
@@ -201,6 +237,7 @@ void SceneBuilder::build_gpu_layout() {
             pair_nodes[i] = p;
         }
     }
+    quantize_pair_nodes(*this);
     // shading records: the instance -> mesh -> index -> attribute chain of gbuffer.wgsl:129-145, flattened per triangle
     shade_tris.assign(tris.size(), ShadeTri{});
     for (size_t id = 0; id < tris.size(); ++id) {

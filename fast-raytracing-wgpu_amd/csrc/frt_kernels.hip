@@ -274,8 +274,8 @@ __device__ __forceinline__ void finish_path(PathCtx& c, uint32_t pix, const Rese
 
 // Runs bounces [d0, d1) of the lane's path and parks a survivor in `q`; when the queue is full the lane goes on to MAX_DEPTH itself.
 // On return the path is either parked (true: state stored) or finished (false: s holds the final radiance).
-template <int VARIANT>
-__device__ __forceinline__ bool run_segment_and_park(PathCtx& c, LoopState& s, uint32_t d0, uint32_t d1, const ContQueue& q, uint32_t pix, bool owned,
+template <int VARIANT, class Ctx>
+__device__ __forceinline__ bool run_segment_and_park(Ctx& c, LoopState& s, uint32_t d0, uint32_t d1, const ContQueue& q, uint32_t pix, bool owned,
                                                      const ReservoirView* r) {
     bool run = s.alive, parked = false;
 #pragma nounroll
@@ -295,7 +295,8 @@ __device__ __forceinline__ bool run_segment_and_park(PathCtx& c, LoopState& s, u
 
 template <int STAGE>
 __global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, TileOrder to, uint32_t* zero_counts) {
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    constexpr int THREADS = kBlock;
+    __shared__ uint32_t s_stack[kStackDepth * THREADS];
     __shared__ uint32_t s_cnt[2];
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameVie
     uint32_t px, py;
     const uint32_t tile_row = ordered_tile_row(to);
     const bool active = tile_pixel_at(fv, blockIdx.x, tile_row, px, py);
-    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
+    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
     const uint32_t pix = py * fv.W + px;
     const bool counted = active && py >= fv.own_y0 && py < fv.own_y1;
     LoopState s;
@@ -331,18 +332,19 @@ __global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameVie
 // Resumes parked paths for bounces [d0, d1); survivors are parked again in `qout` (d1 < MAX_DEPTH) or finished here.
 template <int STAGE>
 __global__ void __launch_bounds__(kBlock, 4) continue_kernel(SceneView sc, FrameView fv, ContQueue qin, ContQueue qout, uint32_t d0, uint32_t d1) {
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    constexpr int THREADS = kBlock;
+    __shared__ uint32_t s_stack[kStackDepth * THREADS];
     __shared__ uint32_t s_cnt[2];
     const uint32_t filled = *qin.count;
     const uint32_t n = filled < qin.capacity ? filled : qin.capacity;
-    if (blockIdx.x * (uint32_t)kBlock >= n) return;   // uniform per workgroup
+    if (blockIdx.x * (uint32_t)THREADS >= n) return;   // uniform per workgroup
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
-    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
+    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
     uint32_t cnt_closest = 0u, cnt_any = 0u;
     // stride loop: one trip with the grid of launch_trace_continuations; uniform per workgroup for any grid
-    for (uint32_t base = blockIdx.x * (uint32_t)kBlock; base < n; base += gridDim.x * (uint32_t)kBlock) {
+    for (uint32_t base = blockIdx.x * (uint32_t)THREADS; base < n; base += gridDim.x * (uint32_t)THREADS) {
         const uint32_t slot_in = base + threadIdx.x;
         LoopState s;
         s.alive = false;
@@ -357,6 +359,235 @@ __global__ void __launch_bounds__(kBlock, 4) continue_kernel(SceneView sc, Frame
         if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
     }
     flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
+}
+
+// Bounce kernel: every bounce of every parked path, with LANE REFILL. The continuation kernels above start dense and thin out: a wave that
+// resumes 64 paths at depth 3 has a dozen left two bounces later (15 % lane utilisation, profiles/r2a_pmc.txt). Here a wave runs ONE bounce
+// per trip of its loop and, before each trip, hands the lanes whose path has ended a fresh parked path from the queue (one atomic per wave
+// and trip; the queue was filled completely by the previous launch, so there is nothing to wait for). Lanes of a wave are then at different
+// depths of different paths — which is fine: a bounce iteration is the same code at every depth (restir.wgsl:590-733), a path's arithmetic
+// and rand() sequence do not depend on the lane that runs it, and the per-lane `depth` feeds the two places that look at it (the v1 capture
+// at depth 1 and the loop bound). The wave stays dense until the queue runs dry; with the cut at depth 1 (the pixel kernel then does the
+// primary hit only) all bounce work of a stage runs this way.
+template <int STAGE>
+__global__ void __launch_bounds__(kBlock, 4) bounce_kernel(SceneView sc, FrameView fv, ContQueue qin, uint32_t* head, uint32_t d0, uint32_t refill_min) {
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    __shared__ uint32_t s_cnt[2];
+    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
+    const uint32_t filled = *qin.count;
+    const uint32_t n = filled < qin.capacity ? filled : qin.capacity;
+    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
+    LoopState s;
+    s.alive = false;
+    s.pos = s.ffnormal = s.throughput = s.accumulated = s.next_dir = s.v1_pos = splat3(0.0f);
+    s.last_bsdf_pdf = 0.0f; s.previous_was_diffuse = false; s.is_glass = false;
+    ReservoirView r = zero_reservoir();
+    uint32_t pix = 0u, depth = d0, cnt_closest = 0u, cnt_any = 0u;
+    bool owned = false, more = true;      // more: the queue may still hold unclaimed paths (wave-uniform)
+    for (;;) {
+        const unsigned long long dead = __ballot(!s.alive);
+        const uint32_t k = (uint32_t)__popcll(dead);
+        if (more && k >= refill_min) {
+            const int leader = __ffsll((long long)dead) - 1;
+            uint32_t base = 0u;
+            if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(head, k);
+            base = __shfl(base, leader, 64);
+            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0u));
+            if (!s.alive && slot < n) {
+                if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }      // the rays of the path this lane ran before
+                c.n_closest = 0u; c.n_any = 0u;
+                cont_load(qin, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+                depth = d0;
+            }
+            if (base + k >= n) more = false;
+        }
+        if (__ballot(s.alive) == 0ull) {
+            if (!more) break;
+            continue;      // (only when refill_min > the dead lanes of an all-dead wave, i.e. never: 64 >= refill_min)
+        }
+        if (s.alive) {
+            path_loop<VARIANT>(c, s, depth, depth + 1u);
+            depth += 1u;
+            if (!s.alive) finish_path<STAGE>(c, pix, r, s);
+        }
+    }
+    if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
+    flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
+}
+
+// ---- resident kernels: the BVH lives in LDS ---------------------------------------------------------------------------------------
+// Same stages, same arithmetic, another execution shape. One persistent 1024-thread workgroup per CU (16 waves = the 4 waves per SIMD the
+// register budget allows anyway) first copies the quantized pair nodes — all of them when they fit, the top of the breadth-first tree
+// otherwise — and, when there is room, every triangle slot into LDS (Cornell Box: 25 KB + 62 KB next to 64 KB of traversal stacks), then
+// each WAVE takes 16x16 pixel blocks from a global counter (four 8x8 tiles one after the other) until the counter runs out.
+//  * a node step is two ds_read_b128 (~100 cycles, no TA / L1 / L2 round trip) instead of four global loads (~500-900 cycles under
+//    load); a triangle test three ds_read_b128. The vector-memory pipe keeps the per-pixel streams, shading records and the queues.
+//  * waves are independent: no workgroup waits for its slowest wave, and the sweep over the image is the order of the counter.
+// Used when the tree is shallow enough for the 16-entry stacks (bvh_depth <= 17); deeper trees take pixel_kernel / continue_kernel.
+static constexpr int kResThreads = 1024, kResStack = 16;
+struct ResidentArgs {
+    uint32_t n_lds;        // pair nodes cached in LDS: [0, n_lds)
+    uint32_t tris_lds;     // 1: all triangle slots cached too
+    uint32_t* work;        // [0] next tile / chunk, [1] ticket of finished workgroups; both zero between launches
+    uint32_t batch;        // 8x8 tiles a wave takes per fetch (4 = a whole 16x16 block; 1 when tiles are scarce)
+};
+// BVH accessor of the resident kernels: LDS-typed pointers (ds_read_b128, not flat loads) for the cached part, HBM for the rest.
+typedef __attribute__((address_space(3))) const uint32_t* lds_u32_ptr;
+typedef __attribute__((address_space(3))) const float* lds_f32_ptr;
+struct LdsBvh {
+    lds_u32_ptr a_lds; lds_u32_ptr b_lds; uint32_t n_lds;    // nodes [0, n_lds) cached in LDS (breadth-first order: the top of the tree)
+    const uint4* a_glb; const uint4* b_glb;                  // every node, in HBM
+    lds_f32_ptr tris_lds; bool tris_cached;                  // every triangle slot cached in LDS, or not at all
+    const float4* tris_glb;
+    f3 qmin, qstep;
+    __device__ __forceinline__ void node(uint32_t i, uint4& qa, uint4& qb) const {
+        if (i < n_lds) {
+            lds_u32_ptr pa = a_lds + 4u * i; lds_u32_ptr pb = b_lds + 4u * i;      // 16-byte aligned: one ds_read_b128 each
+            qa = make_uint4(pa[0], pa[1], pa[2], pa[3]); qb = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+        } else { qa = a_glb[i]; qb = b_glb[i]; }
+    }
+    __device__ __forceinline__ void tri(uint32_t slot, float4& t0, float4& t1, float4& t2) const {
+        if (tris_cached) {
+            lds_f32_ptr p = tris_lds + 12u * slot;
+            t0 = make_float4(p[0], p[1], p[2], p[3]); t1 = make_float4(p[4], p[5], p[6], p[7]); t2 = make_float4(p[8], p[9], p[10], p[11]);
+        } else { const float4* p = tris_glb + (size_t)slot * 3u; t0 = p[0]; t1 = p[1]; t2 = p[2]; }
+    }
+};
+struct ResidentCtx : PathCtx {
+    LdsBvh qb;
+    __device__ __forceinline__ ResidentCtx(const SceneView& s, const FrameView& f, uint32_t* st, uint32_t sd) : PathCtx(s, f, st, sd) {}
+    __device__ __forceinline__ void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) { n_closest++; trace_q<false>(sc, qb, o, d, tmin, tmax, stk, stride, h); }
+    __device__ __forceinline__ bool any(f3 o, f3 d, float tmin, float tmax) { HitRec h; n_any++; trace_q<true>(sc, qb, o, d, tmin, tmax, stk, stride, h); return h.tri != 0xFFFFFFFFu; }
+};
+// Carves the dynamic LDS block (stacks | nodes A | nodes B | triangles), fills the BVH cache. Ends with a barrier.
+__device__ __forceinline__ void resident_setup(const SceneView& sc, const ResidentArgs& ra, uint4* s_dyn, LdsBvh& qb, uint32_t*& stack) {
+    stack = reinterpret_cast<uint32_t*>(s_dyn);
+    uint4* s_a = s_dyn + (kResStack * kResThreads) / 4;
+    uint4* s_b = s_a + ra.n_lds;
+    float4* s_tri = reinterpret_cast<float4*>(s_b + ra.n_lds);
+    for (uint32_t i = threadIdx.x; i < ra.n_lds; i += (uint32_t)kResThreads) { s_a[i] = sc.qnode_a[i]; s_b[i] = sc.qnode_b[i]; }
+    if (ra.tris_lds) for (uint32_t i = threadIdx.x; i < sc.num_tris * 3u; i += (uint32_t)kResThreads) s_tri[i] = sc.tris[i];
+    qb.a_lds = (lds_u32_ptr)s_a; qb.b_lds = (lds_u32_ptr)s_b; qb.n_lds = ra.n_lds; qb.a_glb = sc.qnode_a; qb.b_glb = sc.qnode_b;
+    qb.tris_lds = (lds_f32_ptr)s_tri; qb.tris_cached = ra.tris_lds != 0u; qb.tris_glb = sc.tris;
+    qb.qmin = mk3(sc.qmin[0], sc.qmin[1], sc.qmin[2]); qb.qstep = mk3(sc.qstep[0], sc.qstep[1], sc.qstep[2]);
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t wave_next(uint32_t* counter) {
+    uint32_t v = 0u;
+    if ((threadIdx.x & 63u) == 0u) v = atomicAdd(counter, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+// The last workgroup of a resident launch re-arms the work counters (and, for a pixel launch, decides the next sweep direction).
+__device__ __forceinline__ void resident_finish(const ResidentArgs& ra, const TileOrder* to) {
+    if (threadIdx.x != 0u) return;
+    if (atomicAdd(&ra.work[1], 1u) != gridDim.x - 1u) return;
+    ra.work[0] = 0u; ra.work[1] = 0u;
+    if (to && to->st) {
+        unsigned long long* sums = reinterpret_cast<unsigned long long*>(to->st + 2);
+        const unsigned long long top = atomicExch(&sums[0], 0ull), bottom = atomicExch(&sums[1], 0ull);
+        to->st[0] = top <= bottom ? 1u : 0u;   // the sweep should END on the cheaper eighth of the image
+    }
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(kResThreads, 1) resident_pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, TileOrder to, uint32_t* zero_counts,
+                                                                        ResidentArgs ra) {
+    extern __shared__ uint4 s_dyn[];
+    __shared__ uint32_t s_cnt[2];
+    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    if (zero_counts && blockIdx.x == 0u && threadIdx.x <= (uint32_t)kMaxCuts) zero_counts[threadIdx.x] = 0u;
+    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
+    uint32_t* stack;
+    LdsBvh qb;
+    resident_setup(sc, ra, s_dyn, qb, stack);
+    ResidentCtx c(sc, fv, stack + threadIdx.x, (uint32_t)kResThreads);
+    c.qb = qb;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t bx_n = (fv.W + 15u) / 16u, by_n = (fv.y1 - fv.y0 + 15u) / 16u, nblocks = bx_n * by_n;
+    const bool flip = to.st && to.st[0] != 0u;
+    const uint32_t k8 = by_n / 8u > 0u ? by_n / 8u : 1u;
+    uint32_t cnt_closest = 0u, cnt_any = 0u;
+    const uint32_t ntiles = nblocks * 4u;
+    for (;;) {
+        uint32_t t0 = 0u;
+        if (lane == 0u) t0 = atomicAdd(&ra.work[0], ra.batch);
+        t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0);
+        if (t0 >= ntiles) break;
+        const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+        const uint32_t blk = t0 >> 2;       // (a batch never crosses a block: batch is 1, 2 or 4 and fetches are batch-aligned)
+        uint32_t by = blk / bx_n;
+        const uint32_t bx = blk - by * bx_n;
+        if (flip) by = by_n - 1u - by;
+#pragma nounroll
+        for (uint32_t sub = t0 & 3u; sub < (t0 & 3u) + ra.batch; ++sub) {
+            const uint32_t px = bx * 16u + (sub & 1u) * 8u + (lane & 7u);
+            const uint32_t py = fv.y0 + by * 16u + (sub >> 1) * 8u + (lane >> 3);
+            const bool active = px < fv.W && py < fv.y1;
+            if (__ballot(active) == 0ull) continue;
+            const uint32_t pix = py * fv.W + px;
+            const bool counted = active && py >= fv.own_y0 && py < fv.own_y1;
+            LoopState s;
+            s.alive = false;
+            ReservoirView r = zero_reservoir();
+            bool traced = false;
+            c.n_closest = 0u; c.n_any = 0u;
+            if (active) {
+                uint32_t seed = 0u;
+                if (STAGE == 1) {
+                    if (!(fv.gpos[pix].w < 0.0f)) { seed = temporal_seed(fv, pix); traced = true; }
+                } else if (spatial_neighbors(c, pix, r)) { seed = r.y; traced = true; }
+                if (traced) path_head<VARIANT>(c, pix, seed, s);
+            }
+            const bool parked = run_segment_and_park<VARIANT>(c, s, 1u, cut < fv.max_depth ? cut : fv.max_depth, q, pix, counted, STAGE == 2 ? &r : nullptr);
+            if (traced && !parked) finish_path<STAGE>(c, pix, r, s);
+            if (counted) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
+        }
+        if (to.st && lane == 0u) {      // this batch's time, for the next launch's sweep direction (see report_tile_cost)
+            const unsigned long long cost = (__builtin_amdgcn_s_memtime() - t_begin) >> 8;
+            unsigned long long* sums = reinterpret_cast<unsigned long long*>(to.st + 2);
+            if (by < k8) atomicAdd(&sums[0], cost);
+            if (by + k8 >= by_n) atomicAdd(&sums[1], cost);
+        }
+    }
+    flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);   // (contains a barrier preceded by s_waitcnt vmcnt(0): this workgroup's atomics are performed)
+    resident_finish(ra, &to);
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(kResThreads, 1) resident_continue_kernel(SceneView sc, FrameView fv, ContQueue qin, ContQueue qout, uint32_t d0, uint32_t d1, ResidentArgs ra) {
+    extern __shared__ uint4 s_dyn[];
+    __shared__ uint32_t s_cnt[2];
+    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
+    const uint32_t filled = *qin.count;
+    const uint32_t n = filled < qin.capacity ? filled : qin.capacity;
+    uint32_t* stack;
+    LdsBvh qb;
+    resident_setup(sc, ra, s_dyn, qb, stack);
+    ResidentCtx c(sc, fv, stack + threadIdx.x, (uint32_t)kResThreads);
+    c.qb = qb;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t cnt_closest = 0u, cnt_any = 0u;
+    for (;;) {
+        const uint32_t chunk = wave_next(&ra.work[0]);
+        if ((unsigned long long)chunk * 64ull >= (unsigned long long)n) break;
+        const uint32_t slot_in = chunk * 64u + lane;
+        LoopState s;
+        s.alive = false;
+        ReservoirView r = zero_reservoir();
+        uint32_t pix = 0u;
+        bool owned = false;
+        c.n_closest = 0u; c.n_any = 0u;
+        const bool have = slot_in < n;
+        if (have) cont_load(qin, slot_in, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+        const bool parked = run_segment_and_park<VARIANT>(c, s, d0, d1, qout, pix, owned, STAGE == 2 ? &r : nullptr);
+        if (have && !parked) finish_path<STAGE>(c, pix, r, s);
+        if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
+    }
+    flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
+    resident_finish(ra, nullptr);
 }
 
 // T-merge (frt_path.hpp: temporal_merge): RIS of the fresh candidate with the reprojected previous spatial reservoir, one thread
@@ -462,10 +693,30 @@ hipError_t launch_compact(int stage, const SceneView& sc, const FrameView& fv, h
 // Pixel kernel of a traced stage over rows [fv.y0, fv.y1) (fv.y0 on the stage's 16-row tile grid). A stage may be launched in
 // several row ranges (a strip's interior before its halo-dependent edge rows): they share the queue; only one of them should
 // carry the tile-order state (L.tile_state) and the counter clearing (L.zero_counts).
+static uint32_t resident_lds_bytes(const SceneView& sc, const TraceLaunch& L) {
+    return (uint32_t)(kResStack * kResThreads * 4) + L.res_nodes * 32u + (L.res_tris ? sc.num_tris * 48u : 0u);
+}
+template <class K>
+static hipError_t allow_lds(K kernel, uint32_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 hipError_t launch_trace_pixels(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const TraceLaunch& L) {
     if (stage != 1 && stage != 2) return hipErrorInvalidValue;
     if (empty_rows(fv)) return hipSuccess;
     const dim3 grid = grid_for(fv);
+    if (L.resident) {
+        TileOrder to{L.tile_state, grid.y};
+        const uint32_t lds = resident_lds_bytes(sc, L), ntiles = grid.x * grid.y * 4u, waves = L.num_cus * (uint32_t)(kResThreads / 64);
+        uint32_t batch = L.res_batch ? L.res_batch : (ntiles >= 6u * waves ? 2u : 1u);
+        if (batch != 1u && batch != 2u && batch != 4u) batch = 1u;
+        ResidentArgs ra{L.res_nodes, L.res_tris ? 1u : 0u, L.work, batch};
+        const uint32_t wgs = std::max(1u, std::min(L.num_cus, (ntiles / batch + 15u) / 16u));
+        hipError_t e = stage == 1 ? allow_lds(resident_pixel_kernel<1>, lds) : allow_lds(resident_pixel_kernel<2>, lds);
+        if (e != hipSuccess) return e;
+        if (stage == 1) hipLaunchKernelGGL(resident_pixel_kernel<1>, dim3(wgs), dim3(kResThreads), lds, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), to, L.zero_counts, ra);
+        else hipLaunchKernelGGL(resident_pixel_kernel<2>, dim3(wgs), dim3(kResThreads), lds, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), to, L.zero_counts, ra);
+        return hipGetLastError();
+    }
     TileOrder to{L.tile_state, grid.y};
     if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), to, L.zero_counts);
     else hipLaunchKernelGGL(pixel_kernel<2>, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), to, L.zero_counts);
@@ -473,16 +724,39 @@ hipError_t launch_trace_pixels(int stage, const SceneView& sc, const FrameView& 
 }
 bool trace_has_continuations(const TraceLaunch& L, uint32_t max_depth) { return L.ncuts > 0 && L.cuts[0] < max_depth; }
 // One continuation launch per further path segment, each over min(queue length, capacity) parked paths (the grid covers the capacity;
-// workgroups beyond the queue's length leave at once).
+// workgroups beyond the queue's length leave at once). Resident form: persistent workgroups take 64-path chunks from a counter.
 hipError_t launch_trace_continuations(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const TraceLaunch& L) {
     if (stage != 1 && stage != 2) return hipErrorInvalidValue;
+    if (L.refill && L.ncuts == 1 && L.cuts[0] < fv.max_depth) {
+        // one bounce kernel with lane refill instead of the continuation launches: persistent waves, 4 workgroups per CU
+        const uint32_t wgs = std::max(1u, std::min(L.num_cus * 4u, (L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock));
+        if (stage == 1) hipLaunchKernelGGL(bounce_kernel<1>, dim3(wgs), dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), L.counts + 1, L.cuts[0], L.refill_min);
+        else hipLaunchKernelGGL(bounce_kernel<2>, dim3(wgs), dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), L.counts + 1, L.cuts[0], L.refill_min);
+        return hipGetLastError();
+    }
     const dim3 cgrid((L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
     for (uint32_t k = 0; k < L.ncuts && L.cuts[k] < fv.max_depth; ++k) {
         const uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
-        if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, cgrid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1);
+        if (L.resident) {
+            ResidentArgs ra{L.res_nodes, L.res_tris ? 1u : 0u, L.work + 2u * (3u + k), 1u};      // behind the three pixel-launch pairs (L.work = the stage's slot 0)
+            const uint32_t lds = resident_lds_bytes(sc, L);
+            const uint32_t wgs = std::max(1u, std::min(L.num_cus, (L.capacity + 1023u) / 1024u));
+            hipError_t e = stage == 1 ? allow_lds(resident_continue_kernel<1>, lds) : allow_lds(resident_continue_kernel<2>, lds);
+            if (e != hipSuccess) return e;
+            if (stage == 1) hipLaunchKernelGGL(resident_continue_kernel<1>, dim3(wgs), dim3(kResThreads), lds, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1, ra);
+            else hipLaunchKernelGGL(resident_continue_kernel<2>, dim3(wgs), dim3(kResThreads), lds, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1, ra);
+        } else if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, cgrid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1);
         else hipLaunchKernelGGL(continue_kernel<2>, cgrid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1);
     }
     return hipGetLastError();
+}
+// How much of the scene's BVH a resident launch can keep in LDS next to its stacks: (nodes, all triangles?). (0, false): not resident.
+void resident_plan(const SceneView& sc, uint32_t& nodes, bool& tris) {
+    nodes = 0u; tris = false;
+    if (sc.bvh_depth > (uint32_t)kResStack + 1u || !sc.qnode_a) return;
+    const uint32_t budget = 163840u - 256u - (uint32_t)(kResStack * kResThreads * 4);
+    if (sc.num_nodes * 32u + sc.num_tris * 48u <= budget) { nodes = sc.num_nodes; tris = true; return; }
+    nodes = std::min(sc.num_nodes, budget / 32u);
 }
 
 } // namespace frt

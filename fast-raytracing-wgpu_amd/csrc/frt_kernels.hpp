@@ -10,12 +10,18 @@ namespace frt {
 // `tile_state`: the stage's sweep-direction state (frt_kernels.hip: TileOrder) or null = tile rows top to bottom.
 static constexpr int kMaxCuts = 4;
 struct TraceLaunch { uint32_t ncuts; uint32_t cuts[kMaxCuts]; uint32_t* qwords[2]; uint32_t* counts; uint32_t capacity; uint32_t* overflow;
-                     uint32_t* zero_counts; uint32_t* tile_state; };
+                     uint32_t* zero_counts; uint32_t* tile_state;
+                     // resident form (frt_kernels.hip: resident_*_kernel): BVH cached in LDS, persistent workgroups
+                     bool refill; uint32_t refill_min;   // single cut: bounce_kernel (lane refill) instead of the continuation launches; refill when >= refill_min lanes are free
+                     bool resident; uint32_t res_nodes; bool res_tris; uint32_t num_cus; uint32_t res_batch;   // res_batch: 0 = chosen from the tile count
+                     uint32_t* work; };   // 2 x (1 + kMaxCuts) words: {next, ticket} of the pixel launch, then of each continuation launch; zero between launches
 // All launches are asynchronous on `stream` and cover rows [fv.y0, fv.y1).
 hipError_t launch_gbuffer(const SceneView& sc, const FrameView& fv, hipStream_t stream);
 hipError_t launch_trace_pixels(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const TraceLaunch& L);
 bool trace_has_continuations(const TraceLaunch& L, uint32_t max_depth);
 hipError_t launch_trace_continuations(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const TraceLaunch& L);
+// LDS plan of the resident kernels for this scene: pair nodes cached (0 = the scene does not qualify), all triangle slots cached?
+void resident_plan(const SceneView& sc, uint32_t& nodes, bool& tris);
 // T-merge; `pending` (may be null): four ray counters {G closest, G any, T-trace closest, T-trace any} of a G-buffer + T-trace pair that
 // ran ahead of its frame, added to `committed` and cleared.
 hipError_t launch_merge(const SceneView& sc, const FrameView& fv, hipStream_t stream, unsigned long long* pending, unsigned long long* committed);

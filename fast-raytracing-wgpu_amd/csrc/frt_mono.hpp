@@ -11,19 +11,16 @@ struct Surf {        // HitInfo subset, restir.wgsl:81-90
 };
 
 // restir.wgsl:375-381 (VARIANT 0) vs restir_spatial.wgsl:380-400 (VARIANT 1). true = unoccluded.
-template <int VARIANT>
-FRT_HD bool trace_shadow_ray(PathCtx& c, f3 origin, f3 dir, float dist) {
+template <int VARIANT, class Ctx>
+FRT_HD bool trace_shadow_ray(Ctx& c, f3 origin, f3 dir, float dist) {
     float t_max = fmaxn(dist * 0.999f, 0.0f);
     float t_min = VARIANT == 0 ? 0.001f : 0.0001f;
     if (VARIANT == 1 && t_min >= t_max) return true;
-    HitRec h;
-    c.n_any++;
-    trace<true>(c.sc, origin, dir, t_min, t_max, c.stk, c.stride, h);
-    return h.tri == 0xFFFFFFFFu;
+    return !c.any(origin, dir, t_min, t_max);
 }
 
-template <int VARIANT>
-FRT_HD f3 eval_direct_lighting(PathCtx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_color, const LightSmp& ls, float weight) {   // :443-459
+template <int VARIANT, class Ctx>
+FRT_HD f3 eval_direct_lighting(Ctx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_color, const LightSmp& ls, float weight) {   // :443-459
     f3 offset_pos = hit.pos + hit.ffnormal * 0.001f;
     f3 L = normalize(ls.pos - offset_pos);
     float dist = distance(ls.pos, offset_pos);
@@ -38,8 +35,8 @@ FRT_HD f3 eval_direct_lighting(PathCtx& c, const Surf& hit, f3 wo, const MatPara
     }
     return splat3(0.0f);
 }
-template <int VARIANT>
-FRT_HD f3 nee(PathCtx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_color, f3 throughput) {   // :558-571 == :707-720
+template <int VARIANT, class Ctx>
+FRT_HD f3 nee(Ctx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_color, f3 throughput) {   // :558-571 == :707-720
     uint32_t nl = c.fv.cam.num_lights;
     if (nl > 0u) {
         uint32_t light_idx = (uint32_t)(c.rand() * (float)nl);
@@ -66,8 +63,8 @@ struct LoopState {
 
 // restir.wgsl:460-584 (VARIANT 0) / restir_spatial.wgsl:480-610 (VARIANT 1): the primary hit, read from the G-buffer.
 // Returns with s.alive == false when the path ended here (background, light surface, zero BSDF weight).
-template <int VARIANT>
-FRT_HD void path_head(PathCtx& c, uint32_t pix, uint32_t seed, LoopState& s) {
+template <int VARIANT, class Ctx>
+FRT_HD void path_head(Ctx& c, uint32_t pix, uint32_t seed, LoopState& s) {
     const SceneView& sc = c.sc; const FrameView& fv = c.fv;
     c.rng = seed;
     s.accumulated = splat3(0.0f); s.v1_pos = splat3(0.0f); s.throughput = splat3(1.0f); s.next_dir = splat3(0.0f);
@@ -143,8 +140,8 @@ FRT_HD void path_head(PathCtx& c, uint32_t pix, uint32_t seed, LoopState& s) {
 
 // Bounce loop, iterations depth_begin .. depth_end-1 of `for (depth = 1; depth < MAX_DEPTH; depth++)` (restir.wgsl:590-733).
 // On return s.alive tells whether the path is still running (it reached depth_end without terminating).
-template <int VARIANT>
-FRT_HD void path_loop(PathCtx& c, LoopState& s, uint32_t depth_begin, uint32_t depth_end) {
+template <int VARIANT, class Ctx>
+FRT_HD void path_loop(Ctx& c, LoopState& s, uint32_t depth_begin, uint32_t depth_end) {
     const SceneView& sc = c.sc; const FrameView& fv = c.fv;
     Surf hit;
     hit.pos = s.pos; hit.ffnormal = s.ffnormal; hit.normal = s.ffnormal; hit.front_face = true;
@@ -159,8 +156,7 @@ FRT_HD void path_loop(PathCtx& c, LoopState& s, uint32_t depth_begin, uint32_t d
         f3 offset_dir = hit.ffnormal * signf(dot(hit.ffnormal, next_dir));
         f3 origin = hit.pos + offset_dir * 0.001f;
         HitRec h;
-        c.n_closest++;
-        trace<false>(sc, origin, next_dir, 0.001f, 100.0f, c.stk, c.stride, h);
+        c.closest(origin, next_dir, 0.001f, 100.0f, h);
         if (h.tri == 0xFFFFFFFFu) break;
         HitGeom g = fetch_hit_geometry(sc, h);   // reconstruct_geometry_hit, :383-441
         hit.normal = g.normal_w;
@@ -306,7 +302,8 @@ FRT_HD void temporal_pixel(PathCtx& c, uint32_t px, uint32_t py) {
 
 // spatial: restir_spatial.wgsl:857-1016. Neighbour loop (:912-993) -> merged reservoir r; [trace_path(r.y)] -> spatial_finalize.
 // false: background pixel (outputs written).
-FRT_HD bool spatial_neighbors(PathCtx& c, uint32_t pix, ReservoirView& r) {
+template <class Ctx>
+FRT_HD bool spatial_neighbors(Ctx& c, uint32_t pix, ReservoirView& r) {
     SpatialState ss;
     if (!spatial_begin(c, ss, pix)) return false;
     while (ss.i < ss.n) {
@@ -314,12 +311,7 @@ FRT_HD bool spatial_neighbors(PathCtx& c, uint32_t pix, ReservoirView& r) {
         req.want = false; req.o = splat3(0.0f); req.d = splat3(0.0f); req.tmin = 0.0f; req.tmax = 0.0f;
         spatial_neighbor_prepare(c, ss, req);
         bool visible = true;
-        if (req.want) {
-            HitRec h;
-            c.n_any++;
-            trace<true>(c.sc, req.o, req.d, req.tmin, req.tmax, c.stk, c.stride, h);
-            visible = h.tri == 0xFFFFFFFFu;
-        }
+        if (req.want) visible = !c.any(req.o, req.d, req.tmin, req.tmax);
         spatial_neighbor_finish(ss, visible);
     }
     r = ss.r;

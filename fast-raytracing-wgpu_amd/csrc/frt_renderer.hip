@@ -68,6 +68,10 @@ struct frt_renderer {
     uint32_t qparity[2] = {0, 0};
     uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box
     uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state, or null
+    bool refill = false; uint32_t refill_min = 16;   // bounce kernel with lane refill (single cut) instead of continuation launches
+    bool resident = false;                 // traced stages through the resident kernels (BVH cached in LDS, persistent workgroups)
+    uint32_t res_nodes = 0; bool res_tris = false; uint32_t num_cus = 0, res_batch = 0;
+    uint32_t* d_work = nullptr;            // work counters of the resident launches: [stage 1|2][launch slot][2]
     frt_stats stats{};
     struct Timed { hipEvent_t a, b; int slot; };
     std::vector<Timed> pending;
@@ -112,6 +116,10 @@ static int upload_scene(frt_renderer* r, const SceneBuilder& b) {
     int rc;
     if ((rc = upload(r, b.pair_nodes, &sv.nodes))) return rc;
     if ((rc = upload(r, b.tri_slots, &sv.tris))) return rc;
+    if ((rc = upload(r, b.qnode_a, &sv.qnode_a))) return rc;
+    if ((rc = upload(r, b.qnode_b, &sv.qnode_b))) return rc;
+    for (int a = 0; a < 3; ++a) { sv.qmin[a] = b.qmin[a]; sv.qstep[a] = b.qstep[a]; }
+    sv.bvh_depth = b.bvh_depth;
     if ((rc = upload(r, b.shade_tris, &sv.shade_tris))) return rc;
     if ((rc = upload(r, b.instances_dev, &sv.instances))) return rc;
     if ((rc = upload(r, b.mesh_infos, &sv.mesh_infos))) return rc;
@@ -397,10 +405,13 @@ void frt_renderer_destroy(frt_renderer* r) {
     free_queues(r);
     if (r->d_qcount) (void)hipFree(r->d_qcount);
     if (r->d_tiles) (void)hipFree(r->d_tiles);
+    if (r->d_work) (void)hipFree(r->d_work);
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
 
+static const int kWorkSlots = 3 + kMaxCuts;                       // pixel launch (interior / whole), the two edge launches, one per continuation launch
+static const size_t kWorkWords = 2 * kWorkSlots * 2;               // [stage][slot]{next, ticket}
 static const size_t kQcountWords = 2 * 2 * (kMaxCuts + 1) + 2;   // [stage][parity][segment] counters + [stage] overflow counters
 static bool stage_is_cut(const frt_renderer* r) { return r->ncuts > 0 && r->cuts[0] < r->max_depth && !(r->flags & FRT_FLAG_COMPACTION); }
 
@@ -494,6 +505,19 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, C_COUNT * sizeof(unsigned long long), r->stream));
     int rc = upload_scene(r, s->b);
     if (rc) return rc;
+    {   // resident kernels: when the tree is shallow enough for their 16-entry stacks (FRT_RESIDENT=0: experiment knob, the plain kernels)
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+        r->num_cus = (uint32_t)prop.multiProcessorCount;
+        resident_plan(r->sv, r->res_nodes, r->res_tris);
+        r->resident = r->res_nodes > 0 && !(r->flags & FRT_FLAG_COMPACTION);
+        if (const char* e = getenv("FRT_RESIDENT")) { if (atoi(e) == 0) r->resident = false; }
+        if (const char* e = getenv("FRT_REFILL")) { r->refill = atoi(e) != 0; if (atoi(e) > 1) r->refill_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: 0 off, 1 on, n > 1: refill when >= n lanes are free
+        if (const char* e = getenv("FRT_RES_BATCH")) r->res_batch = (uint32_t)atoi(e);      // experiment knob: tiles per fetch (1, 2, 4)
+        if (const char* e = getenv("FRT_RES_TRIS")) { if (atoi(e) == 0) r->res_tris = false; }   // experiment knob: triangles from L2
+        HIP_TRY(hipMalloc((void**)&r->d_work, kWorkWords * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(r->d_work, 0, kWorkWords * sizeof(uint32_t), r->stream));
+    }
     HIP_TRY(hipStreamSynchronize(r->stream));
     return FRT_OK;
 }
@@ -532,8 +556,13 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
 // simply overwritten, its counts cleared) and the stages run in order on the main stream. Same pixels either way.
 // Buffer hazards: G-buffer slot (f+1)&1 and the candidate buffer are last read by T-merge(f) and post(f-1), the motion slot by post(f-1):
 // all on the main stream before spatial pixels(f), which the ahead stream waits for (ev_spix); everything else stays on the main stream.
-static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, TraceLaunch& L) {
+// work_slot: which pair of work counters a resident PIXEL launch uses (0 interior / whole stage, 1 and 2 the edge launches, which may
+// run beside the interior one); the continuation launches use the pairs behind them.
+static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, TraceLaunch& L, int work_slot = 0) {
     memset(&L, 0, sizeof(L));
+    L.refill = r->refill; L.refill_min = r->refill_min;
+    L.resident = r->resident; L.res_nodes = r->res_nodes; L.res_tris = r->res_tris; L.num_cus = r->num_cus; L.res_batch = r->res_batch;
+    L.work = r->d_work + ((size_t)(stage - 1) * kWorkSlots + (size_t)work_slot) * 2;
     const bool cut = stage_is_cut(r) && r->qcap > 0;
     L.ncuts = cut ? r->ncuts : 0u;
     for (int k = 0; k < kMaxCuts; ++k) L.cuts[k] = r->cuts[k];
@@ -714,10 +743,13 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
                 hipStream_t q = r->stream;
                 const bool any_edge = (ia > y0) || (y1 > ib);
                 if (r->edge && any_edge && ia < ib) { q = r->edge; HIP_TRY(hipStreamWaitEvent(r->edge, r->ev_tm, 0)); }
+                int slot = 1;
                 for (const auto& e : edge) {
+                    const int this_slot = slot++;
                     if (e[1] <= e[0]) continue;
                     L.zero_counts = need_clear ? zc : nullptr;
                     need_clear = false;
+                    L.work = r->d_work + ((size_t)kWorkSlots + (size_t)this_slot) * 2;     // stage 2, its own counters
                     fv.y0 = e[0]; fv.y1 = e[1];
                     HIP_TRY(launch_trace_pixels(2, r->sv, fv, q, L));
                 }
@@ -808,6 +840,7 @@ int frt_renderer_clear(frt_renderer* r) {
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, C_COUNT * sizeof(unsigned long long), r->stream));
     HIP_TRY(hipMemsetAsync(r->d_qcount, 0, kQcountWords * sizeof(uint32_t), r->stream));
+    HIP_TRY(hipMemsetAsync(r->d_work, 0, kWorkWords * sizeof(uint32_t), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     rc = init_tile_state(r);
     if (rc) return rc;

@@ -106,6 +106,8 @@ public:
     std::vector<uint32_t> bvh2_tri_index;
     uint32_t bvh_depth = 0, bvh_leaves = 0, bvh_max_leaf = 0;
     std::vector<PairNode> pair_nodes;
+    std::vector<uint32_t> qnode_a, qnode_b;     // quantized pair nodes, 4 words per node each (frt_trace.hpp: QBvh)
+    float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     std::vector<TriSlot> tri_slots;
     std::vector<ShadeTri> shade_tris;
     std::vector<InstanceDev> instances_dev;

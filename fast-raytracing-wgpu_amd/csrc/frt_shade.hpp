@@ -56,6 +56,10 @@ struct PathCtx {
     uint32_t n_closest, n_any;  // rays issued by this lane
     FRT_HD PathCtx(const SceneView& s, const FrameView& f, uint32_t* st, uint32_t sd) : sc(s), fv(f), stk(st), stride(sd), rng(0), n_closest(0), n_any(0) {}
     FRT_HD float rand() { rng = pcg_hash(rng); return (float)rng / 4294967296.0f; }   // restir.wgsl:138-141 (literal rounds to 2^32)
+    // The two ray queries of the shaders (rayQueryInitialize ... rayQueryGetCommittedIntersection). Functions that trace are templates on
+    // the context type and call these, so that a kernel can substitute its own traversal (frt_kernels.hip: ResidentCtx walks a BVH cached in LDS).
+    FRT_HD void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) { n_closest++; trace<false>(sc, o, d, tmin, tmax, stk, stride, h); }
+    FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) { HitRec h; n_any++; trace<true>(sc, o, d, tmin, tmax, stk, stride, h); return h.tri != 0xFFFFFFFFu; }
 };
 
 FRT_HD float rand_lcg(uint32_t& state) {   // restir.wgsl:781-786

@@ -39,6 +39,10 @@ struct SceneView {
     const uint8_t* data_tex;    // layers of 1024*1024*4 bytes (unorm8)
     const float* srgb_lut;      // 256 floats
     uint32_t num_materials, num_lights, num_nodes, num_tris;
+    // quantized pair nodes (frt_bvh.cpp: quantize_pair_nodes): two 16-byte halves per node, SoA
+    const uint4* qnode_a; const uint4* qnode_b;
+    float qmin[3], qstep[3];
+    uint32_t bvh_depth;
 };
 
 struct HitRec {
@@ -123,6 +127,85 @@ FRT_HD void trace(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint3
         for (uint32_t k = 0; k < count; ++k) {
             const float4* tp = sc.tris + (size_t)(first + k) * 3u;
             float4 a = tp[0], b = tp[1], c = tp[2];
+            float t, u, v, det;
+            if (intersect_tri(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, d, tmin, tmax, t, u, v, det)) {
+                uint32_t id = f2u(a.w);
+                if (ANY) { hit.tri = id; hit.t = t; return; }
+                if (t < hit.t || (t == hit.t && id < hit.tri)) {
+                    hit.t = t; hit.u = u; hit.v = v; hit.tri = id; hit.inst = f2u(b.w); best_det = det;
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = stk[(uint32_t)sp * stride];
+    }
+    if (!ANY && hit.tri != 0xFFFFFFFFu) {
+        bool front = best_det > 0.0f;
+        if (sc.instances[hit.inst].flip) front = !front;
+        hit.front = front;
+    }
+}
+
+// ---- quantized pair nodes, cacheable in LDS -----------------------------------------------------------------------------------
+// A pair node holds the boxes of both children on a 16-bit grid over the scene box: 2 x (6 x u16 + child reference) = 32 bytes, half the
+// float form, and 25 KB for the whole Cornell Box tree: it fits in LDS next to the triangle slots. Boxes are rounded OUTWARD by one
+// extra quantum on the host, so the quantized tree prunes a little less than the float tree and never more; which triangles are hit is
+// decided by the exact triangle test alone (hit semantics above), so results are bit-identical to trace().
+//   half A: x = lo0.x | lo0.y << 16, y = lo0.z | hi0.x << 16, z = hi0.y | hi0.z << 16, w = reference of child 0;   half B: child 1
+// The ray is moved into grid units once (inv_q = qstep * inv, oinv_q = (qmin - o) * inv); a box test then costs 6 conversions + 6 fma.
+// Accessor over plain memory (HBM on the device, host arrays in tests/hostcheck). The resident kernels use their own accessor with
+// LDS-typed pointers (frt_kernels.hip: LdsBvh); trace_q is a template on the accessor so that each gets the right load instructions.
+struct QBvh {
+    const uint4* a; const uint4* b;     // the two halves of every quantized pair node
+    const float4* tris;                 // triangle slots, 3 x float4 each
+    f3 qmin, qstep;
+    FRT_HD void node(uint32_t i, uint4& qa, uint4& qb) const { qa = a[i]; qb = b[i]; }
+    FRT_HD void tri(uint32_t slot, float4& t0, float4& t1, float4& t2) const { const float4* p = tris + (size_t)slot * 3u; t0 = p[0]; t1 = p[1]; t2 = p[2]; }
+};
+FRT_HD bool slab_q(uint32_t w0, uint32_t w1, uint32_t w2, f3 inv, f3 oinv, float tmin, float tlim, float& tnear) {
+    float lox = (float)(w0 & 0xFFFFu), loy = (float)(w0 >> 16), loz = (float)(w1 & 0xFFFFu);
+    float hix = (float)(w1 >> 16), hiy = (float)(w2 & 0xFFFFu), hiz = (float)(w2 >> 16);
+    return slab(lox, loy, loz, hix, hiy, hiz, inv, oinv, tmin, tlim, tnear);
+}
+template <bool ANY, class Bvh>
+FRT_HD void trace_q(const SceneView& sc, const Bvh& bv, f3 o, f3 d, float tmin, float tmax, uint32_t* stk, uint32_t stride, HitRec& hit) {
+    hit.t = tmax; hit.tri = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f; hit.inst = 0u; hit.front = false;
+    float best_det = 0.0f;
+    const float kTiny = 8.271806125530277e-25f;
+    f3 inv = mk3(1.0f / (fabsf_(d.x) > kTiny ? d.x : __builtin_copysignf(kTiny, d.x)),
+                 1.0f / (fabsf_(d.y) > kTiny ? d.y : __builtin_copysignf(kTiny, d.y)),
+                 1.0f / (fabsf_(d.z) > kTiny ? d.z : __builtin_copysignf(kTiny, d.z)));
+    f3 oinv = mk3((bv.qmin.x - o.x) * inv.x, (bv.qmin.y - o.y) * inv.y, (bv.qmin.z - o.z) * inv.z);
+    inv = mk3(inv.x * bv.qstep.x, inv.y * bv.qstep.y, inv.z * bv.qstep.z);
+    const uint32_t kDone = 0xFFFFFFFFu;
+    int sp = 0;
+    uint32_t cur = 0u;
+    for (;;) {
+        while (!(cur & 0x80000000u)) {
+            uint4 qa, qb;
+            bv.node(cur, qa, qb);
+            float tlim = ANY ? tmax : hit.t;
+            float t0, t1;
+            bool h0 = slab_q(qa.x, qa.y, qa.z, inv, oinv, tmin, tlim, t0);
+            bool h1 = slab_q(qb.x, qb.y, qb.z, inv, oinv, tmin, tlim, t1);
+            uint32_t r0 = qa.w, r1 = qb.w;
+            h0 = h0 && (r0 != kDone);
+            h1 = h1 && (r1 != kDone);
+            if (h0 && h1) {
+                bool swap = t1 < t0;
+                uint32_t nearr = swap ? r1 : r0, farr = swap ? r0 : r1;
+                stk[(uint32_t)sp * stride] = farr; ++sp;
+                cur = nearr;
+            } else if (h0) cur = r0;
+            else if (h1) cur = r1;
+            else if (sp == 0) cur = kDone;
+            else { --sp; cur = stk[(uint32_t)sp * stride]; }
+        }
+        if (cur == kDone) break;
+        uint32_t first = cur & 0x00FFFFFFu, count = (cur >> 24) & 0x7Fu;
+        for (uint32_t k = 0; k < count; ++k) {
+            float4 a, b, c;
+            bv.tri(first + k, a, b, c);
             float t, u, v, det;
             if (intersect_tri(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, d, tmin, tmax, t, u, v, det)) {
                 uint32_t id = f2u(a.w);

@@ -15,17 +15,17 @@ class HostCheck:
         L.hc_read.restype = C.c_int; L.hc_read.argtypes = [P, C.c_int, C.c_int, P]
         L.hc_rays.argtypes = [P, P]
         L.hc_set_jitter.argtypes = [P, C.c_float, C.c_float]
-        L.hc_trace.argtypes = [P, C.c_int, U32, P, P, C.c_float, P, P, P, P, P]
+        L.hc_trace.argtypes = [P, C.c_int, U32, P, P, C.c_float, P, P, P, P, P, C.c_int]
 
     def renderer(self, scene, w, h, max_depth=8, nthreads=8, state_machine=False):
         return HcRenderer(self, scene, w, h, max_depth, nthreads, state_machine)
 
-    def trace(self, scene, o, d, tmin, tmax, any_hit=False):
+    def trace(self, scene, o, d, tmin, tmax, any_hit=False, quantized=False):
         o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); n = o.shape[0]
         tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float32), (n,)))
         t = np.zeros(n, np.float32); tri = np.zeros(n, np.uint32); uv = np.zeros((n, 2), np.float32); fr = np.zeros(n, np.uint8)
         self.L.hc_trace(scene._h, int(any_hit), n, o.ctypes.data, d.ctypes.data, tmin, tmax.ctypes.data, t.ctypes.data, tri.ctypes.data,
-                        uv.ctypes.data, fr.ctypes.data)
+                        uv.ctypes.data, fr.ctypes.data, int(quantized))
         return t, tri, uv, fr
 
 

@@ -184,19 +184,24 @@ int hc_read(void* p, int buf, int index, void* out) {
 }
 void hc_rays(void* p, unsigned long long out[2]) { out[0] = ((HostCheck*)p)->rays[0]; out[1] = ((HostCheck*)p)->rays[1]; }
 
-// probe: closest / any hits through the product traversal (pair nodes + triangle slots)
+// probe: closest / any hits through the product traversal. quantized = 0: float pair nodes (trace), 1: the 16-bit pair nodes the
+// resident kernels cache in LDS (trace_q), here over host arrays
 void hc_trace(const frt_scene* s, int any, uint32_t n, const float* o, const float* d, float tmin, const float* tmax,
-              float* t_out, uint32_t* tri_out, float* uv_out, uint8_t* front_out) {
+              float* t_out, uint32_t* tri_out, float* uv_out, uint8_t* front_out, int quantized) {
     const SceneBuilder& b = s->b;
     SceneView sv{};
     sv.nodes = reinterpret_cast<const float4*>(b.pair_nodes.data());
     sv.tris = reinterpret_cast<const float4*>(b.tri_slots.data());
     sv.instances = reinterpret_cast<const InstanceView*>(b.instances_dev.data());
+    QBvh qb;
+    qb.a = reinterpret_cast<const uint4*>(b.qnode_a.data()); qb.b = reinterpret_cast<const uint4*>(b.qnode_b.data()); qb.tris = sv.tris;
+    qb.qmin = mk3(b.qmin[0], b.qmin[1], b.qmin[2]); qb.qstep = mk3(b.qstep[0], b.qstep[1], b.qstep[2]);
     uint32_t stack[kStackDepth];
     for (uint32_t i = 0; i < n; ++i) {
         HitRec h;
         f3 oo = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-        if (any) trace<true>(sv, oo, dd, tmin, tmax[i], stack, 1u, h);
+        if (quantized) { if (any) trace_q<true>(sv, qb, oo, dd, tmin, tmax[i], stack, 1u, h); else trace_q<false>(sv, qb, oo, dd, tmin, tmax[i], stack, 1u, h); }
+        else if (any) trace<true>(sv, oo, dd, tmin, tmax[i], stack, 1u, h);
         else trace<false>(sv, oo, dd, tmin, tmax[i], stack, 1u, h);
         t_out[i] = h.tri != 0xFFFFFFFFu ? h.t : -1.0f;
         tri_out[i] = h.tri;
