@@ -417,6 +417,168 @@ __global__ void __launch_bounds__(kBlock, 4) bounce_kernel(SceneView sc, FrameVi
     flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
 }
 
+// Stream kernel: the bounce kernel with the traversal made RESUMABLE, so that a wave stops paying for its slowest ray.
+// Measured with lane refill alone (profiles/r2g_refill_pmc.txt): even when all 64 lanes start every bounce together, lane utilisation stays
+// at 25-27 %. The loss is inside the bounce: incoherent rays need 5 to 40 node steps and a while-while traversal runs until the LAST lane
+// of the wave is done, twice per bounce (closest hit, shadow); the shading between them waits for those stragglers too.
+// Here every lane is a little state machine
+//        CLOSEST --(ray done)--> SHADE --bounce_shade--> SHADOW --(ray done: add the estimate)--> CLOSEST of the next bounce ...
+// and the wave alternates between two kinds of trips: a TRAVERSAL round (a few node steps + one leaf step for every lane that has a ray
+// in flight, shadow or closest alike — same code) and a SHADING trip (bounce_shade, frt_mono.hpp, for the lanes whose closest-hit ray has
+// finished), taken once enough lanes wait for it or nobody is traversing. A ray that needs 40 steps simply stays in flight over several
+// rounds while its neighbours shade, fire their shadow rays and start the next bounce; lanes whose path has ended are refilled from the
+// queue as in bounce_kernel. Per lane the sequence of operations is path_loop's (bounce_shade is checked against path_loop on the CPU,
+// tests/hostcheck "stream"), so pixels and ray counts are unchanged.
+enum : uint32_t { M_IDLE = 0u, M_SHADOW = 1u, M_CLOSEST = 2u, M_SHADE = 3u };
+struct LaneRay { f3 o, d; float tmin, tmax; uint32_t cur; int sp; float t, u, v, det; uint32_t tri, inst; };
+static constexpr int kSliceNodes = 8;      // node steps per traversal round before the wave looks at its lanes again
+
+__device__ __forceinline__ void lane_ray_begin(LaneRay& tr, f3 o, f3 d, float tmin, float tmax) {
+    tr.o = o; tr.d = d; tr.tmin = tmin; tr.tmax = tmax; tr.cur = 0u; tr.sp = 0;
+    tr.t = tmax; tr.u = 0.0f; tr.v = 0.0f; tr.det = 0.0f; tr.tri = 0xFFFFFFFFu; tr.inst = 0u;
+}
+// One traversal round for the lanes with `go` set: up to kSliceNodes node steps (while any of them is at an inner node), then one leaf
+// (all its triangles) for the lanes that hold one. tr.cur == 0xFFFFFFFF afterwards: the ray is finished. Same box / triangle arithmetic and
+// the same visiting order per ray as trace() (frt_trace.hpp): the closest hit and the any-hit answer are the ones trace() finds.
+__device__ __forceinline__ void traverse_round(const SceneView& sc, LaneRay& tr, bool go, bool any_hit, uint32_t* stk, uint32_t stride) {
+    const uint32_t kDone = 0xFFFFFFFFu;
+    const float kTiny = 8.271806125530277e-25f;
+    f3 inv = mk3(1.0f / (fabsf_(tr.d.x) > kTiny ? tr.d.x : __builtin_copysignf(kTiny, tr.d.x)),
+                 1.0f / (fabsf_(tr.d.y) > kTiny ? tr.d.y : __builtin_copysignf(kTiny, tr.d.y)),
+                 1.0f / (fabsf_(tr.d.z) > kTiny ? tr.d.z : __builtin_copysignf(kTiny, tr.d.z)));
+    f3 oinv = mk3(-tr.o.x * inv.x, -tr.o.y * inv.y, -tr.o.z * inv.z);
+#pragma nounroll
+    for (int it = 0; it < kSliceNodes; ++it) {
+        const bool at_node = go && !(tr.cur & 0x80000000u);
+        if (__ballot(at_node) == 0ull) break;
+        if (at_node) {
+            const float4* n = sc.nodes + (size_t)tr.cur * 4u;
+            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            float tlim = any_hit ? tr.tmax : tr.t;
+            float t0, t1;
+            bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, inv, oinv, tr.tmin, tlim, t0);
+            bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, inv, oinv, tr.tmin, tlim, t1);
+            uint32_t r0 = f2u(q3.x), r1 = f2u(q3.y);
+            h0 = h0 && (r0 != kDone);
+            h1 = h1 && (r1 != kDone);
+            if (h0 && h1) {
+                bool swap = t1 < t0;
+                uint32_t nearr = swap ? r1 : r0, farr = swap ? r0 : r1;
+                stk[(uint32_t)tr.sp * stride] = farr; ++tr.sp;
+                tr.cur = nearr;
+            } else if (h0) tr.cur = r0;
+            else if (h1) tr.cur = r1;
+            else if (tr.sp == 0) tr.cur = kDone;
+            else { --tr.sp; tr.cur = stk[(uint32_t)tr.sp * stride]; }
+        }
+    }
+    if (go && (tr.cur & 0x80000000u) && tr.cur != kDone) {
+        const uint32_t first = tr.cur & 0x00FFFFFFu, count = (tr.cur >> 24) & 0x7Fu;
+        bool found = false;
+        for (uint32_t k = 0; k < count && !found; ++k) {
+            const float4* tp = sc.tris + (size_t)(first + k) * 3u;
+            float4 a = tp[0], b = tp[1], c4 = tp[2];
+            float t, u, v, det;
+            if (intersect_tri(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c4.x, c4.y, c4.z), tr.o, tr.d, tr.tmin, tr.tmax, t, u, v, det)) {
+                uint32_t id = f2u(a.w);
+                if (any_hit) { tr.tri = id; tr.t = t; found = true; }
+                else if (t < tr.t || (t == tr.t && id < tr.tri)) { tr.t = t; tr.u = u; tr.v = v; tr.tri = id; tr.inst = f2u(b.w); tr.det = det; }
+            }
+        }
+        if (found || tr.sp == 0) tr.cur = kDone;
+        else { --tr.sp; tr.cur = stk[(uint32_t)tr.sp * stride]; }
+    }
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(kBlock, 4) stream_kernel(SceneView sc, FrameView fv, ContQueue qin, uint32_t* head, uint32_t d0, uint32_t refill_min, uint32_t shade_min) {
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    __shared__ uint32_t s_cnt[2];
+    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
+    const uint32_t filled = *qin.count;
+    const uint32_t n = filled < qin.capacity ? filled : qin.capacity;
+    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
+    LoopState s;
+    s.alive = false;
+    s.pos = s.ffnormal = s.throughput = s.accumulated = s.next_dir = s.v1_pos = splat3(0.0f);
+    s.last_bsdf_pdf = 0.0f; s.previous_was_diffuse = false; s.is_glass = false;
+    ReservoirView r = zero_reservoir();
+    LaneRay tr;
+    lane_ray_begin(tr, splat3(0.0f), splat3(0.0f), 0.0f, 0.0f);
+    f3 contrib = splat3(0.0f), dark = splat3(0.0f);
+    uint32_t pix = 0u, depth = d0, cnt_closest = 0u, cnt_any = 0u, mode = M_IDLE;
+    bool owned = false, more = true;
+    // a lane that has no ray in flight and nothing to shade: next ray of its path, or the path is finished
+    auto next_ray = [&]() {
+        if (s.alive) { c.n_closest++; lane_ray_begin(tr, bounce_origin(s), s.next_dir, 0.001f, 100.0f); mode = M_CLOSEST; }
+        else { finish_path<STAGE>(c, pix, r, s); mode = M_IDLE; }
+    };
+    for (;;) {
+        // ---- refill: lanes whose path has ended take a parked path from the queue
+        const unsigned long long idle = __ballot(mode == M_IDLE);
+        const uint32_t k = (uint32_t)__popcll(idle);
+        if (more && k >= refill_min) {
+            const int leader = __ffsll((long long)idle) - 1;
+            uint32_t base = 0u;
+            if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(head, k);
+            base = __shfl(base, leader, 64);
+            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (mode == M_IDLE && slot < n) {
+                if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
+                c.n_closest = 0u; c.n_any = 0u;
+                cont_load(qin, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+                depth = d0;
+                next_ray();      // (s.alive: a parked path always has its next iteration)
+            }
+            if (base + k >= n) more = false;
+        }
+        const uint32_t n_trav = (uint32_t)__popcll(__ballot(mode == M_SHADOW || mode == M_CLOSEST));
+        const uint32_t n_shade = (uint32_t)__popcll(__ballot(mode == M_SHADE));
+        if (n_trav == 0u && n_shade == 0u) {
+            if (!more) break;
+            continue;
+        }
+        if (n_shade >= shade_min || n_trav == 0u) {
+            // ---- shading trip
+            if (mode == M_SHADE) {
+                HitRec h;
+                h.t = tr.t; h.u = tr.u; h.v = tr.v; h.tri = tr.tri; h.inst = tr.inst; h.front = false;
+                if (h.tri != 0xFFFFFFFFu) {
+                    bool front = tr.det > 0.0f;
+                    if (sc.instances[h.inst].flip) front = !front;
+                    h.front = front;
+                }
+                ShadowReq req;
+                bounce_shade<VARIANT>(c, s, depth, h, req);
+                depth += 1u;
+                if (req.want) {
+                    contrib = req.contrib; dark = req.dark;
+                    c.n_any++;
+                    lane_ray_begin(tr, req.o, req.d, req.tmin, req.tmax);
+                    mode = M_SHADOW;
+                } else {
+                    s.accumulated = s.accumulated + (req.add_now ? req.contrib : req.dark);
+                    next_ray();
+                }
+            }
+        } else {
+            // ---- traversal round
+            const bool go = mode == M_SHADOW || mode == M_CLOSEST;
+            traverse_round(sc, tr, go, mode == M_SHADOW, c.stk, c.stride);
+            if (go && tr.cur == 0xFFFFFFFFu) {
+                if (mode == M_SHADOW) {
+                    s.accumulated = s.accumulated + (tr.tri == 0xFFFFFFFFu ? contrib : dark);
+                    next_ray();
+                } else mode = M_SHADE;
+            }
+        }
+    }
+    if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
+    flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
+}
+
 // ---- resident kernels: the BVH lives in LDS ---------------------------------------------------------------------------------------
 // Same stages, same arithmetic, another execution shape. One persistent 1024-thread workgroup per CU (16 waves = the 4 waves per SIMD the
 // register budget allows anyway) first copies the quantized pair nodes — all of them when they fit, the top of the breadth-first tree
@@ -727,6 +889,12 @@ bool trace_has_continuations(const TraceLaunch& L, uint32_t max_depth) { return 
 // workgroups beyond the queue's length leave at once). Resident form: persistent workgroups take 64-path chunks from a counter.
 hipError_t launch_trace_continuations(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const TraceLaunch& L) {
     if (stage != 1 && stage != 2) return hipErrorInvalidValue;
+    if (L.stream && L.ncuts == 1 && L.cuts[0] < fv.max_depth) {
+        const uint32_t wgs = std::max(1u, std::min(L.num_cus * 4u, (L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock));
+        if (stage == 1) hipLaunchKernelGGL(stream_kernel<1>, dim3(wgs), dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), L.counts + 1, L.cuts[0], L.refill_min, L.shade_min);
+        else hipLaunchKernelGGL(stream_kernel<2>, dim3(wgs), dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), L.counts + 1, L.cuts[0], L.refill_min, L.shade_min);
+        return hipGetLastError();
+    }
     if (L.refill && L.ncuts == 1 && L.cuts[0] < fv.max_depth) {
         // one bounce kernel with lane refill instead of the continuation launches: persistent waves, 4 workgroups per CU
         const uint32_t wgs = std::max(1u, std::min(L.num_cus * 4u, (L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock));

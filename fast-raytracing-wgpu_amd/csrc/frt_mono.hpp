@@ -233,6 +233,147 @@ FRT_HD void path_loop(Ctx& c, LoopState& s, uint32_t depth_begin, uint32_t depth
     s.alive = alive;      // still running: the roulette for iteration depth_end has been passed
 }
 
+// ---- one bounce with its two rays pulled apart (the form the stream kernel runs, frt_kernels.hip) -----------------------------
+// path_loop traces the closest-hit ray, shades, traces the shadow ray of the next-event estimate in the middle of the shading, and
+// goes on. Here one iteration is cut at its rays:   [closest-hit ray]  ->  bounce_shade  ->  [shadow ray]  ->  add the estimate
+// bounce_shade does everything else of the iteration — hit, material, emission, light hit, the estimate's value (as if unoccluded), BSDF
+// sample, the next iteration's roulette — and hands back the shadow ray with the value to add when it is unoccluded. Same operations
+// on the same operands as path_loop: the estimate is a pure function of the hit (evaluating it before the visibility test instead of
+// after changes nothing), it is the only addition to `accumulated` between the light-hit test and the end of the iteration, nothing
+// after it reads `accumulated`, and no ray draws a random number, so the rand() sequence is the reference's.
+// dark: what path_loop adds when the estimate is NOT lit — zero, or zero times the throughput (NaN where the throughput is inf / NaN: the
+// reference's GGX term overflows on the roughness-0.01 box), so that even those paths stay bit-identical.
+struct ShadowReq { bool want; bool add_now; f3 o, d; float tmin, tmax; f3 contrib, dark; };
+
+template <int VARIANT>
+FRT_HD void nee_request(PathCtx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_color, f3 throughput, ShadowReq& req) {   // nee() + eval_direct_lighting() up to the ray
+    req.want = false; req.add_now = false; req.contrib = splat3(0.0f); req.dark = splat3(0.0f);
+    req.o = splat3(0.0f); req.d = splat3(0.0f); req.tmin = 0.0f; req.tmax = 0.0f;
+    uint32_t nl = c.fv.cam.num_lights;
+    if (nl == 0u) return;
+    uint32_t light_idx = (uint32_t)(c.rand() * (float)nl);
+    if (!(light_idx < nl)) return;
+    req.dark = splat3(0.0f) * throughput;      // from here on nee() returns eval_direct_lighting(...) * throughput
+    LightSmp ls = sample_light(c, light_idx);
+    float pdf_nee = ls.pdf * (1.0f / (float)nl);
+    float p_bsdf = eval_pdf(hit.ffnormal, normalize(ls.pos - hit.pos), wo, m, base_color);
+    float mis_weight_nee = pdf_nee / (pdf_nee + p_bsdf);
+    float weight = mis_weight_nee / pdf_nee;
+    f3 offset_pos = hit.pos + hit.ffnormal * 0.001f;
+    f3 L = normalize(ls.pos - offset_pos);
+    float dist = distance(ls.pos, offset_pos);
+    float n_dot_l = fmaxn(dot(hit.ffnormal, L), 0.0f);
+    float l_dot_n = fmaxn(dot(-L, ls.normal), 0.0f);
+    if (n_dot_l > 0.0f && l_dot_n > 0.0f) {
+        float t_max = fmaxn(dist * 0.999f, 0.0f);
+        float t_min = VARIANT == 0 ? 0.001f : 0.0001f;
+        f3 f = eval_bsdf(hit.ffnormal, L, wo, m, base_color);
+        float G = (n_dot_l * l_dot_n) / (dist * dist);
+        req.contrib = (xyz(ls.emission) * ls.emission.w * f * G * weight) * throughput;
+        if (VARIANT == 1 && t_min >= t_max) req.add_now = true;      // restir_spatial.wgsl:380-400: "too close" counts as unoccluded, no ray
+        else { req.want = true; req.o = offset_pos; req.d = L; req.tmin = t_min; req.tmax = t_max; }
+    }
+}
+
+// Origin of the closest-hit ray of the iteration that starts from state `s` (restir.wgsl:600-605).
+FRT_HD f3 bounce_origin(const LoopState& s) {
+    f3 offset_dir = s.ffnormal * signf(dot(s.ffnormal, s.next_dir));
+    return s.pos + offset_dir * 0.001f;
+}
+// Iteration `depth` after its closest-hit ray returned `h` (fired from bounce_origin(s) along s.next_dir). Leaves s as path_loop would
+// at the end of the iteration (s.alive: the next iteration exists and its roulette has been passed) except for the estimate, which the
+// caller adds:  s.accumulated += (req.add_now || (req.want && unoccluded)) ? req.contrib : req.dark.
+template <int VARIANT>
+FRT_HD void bounce_shade(PathCtx& c, LoopState& s, uint32_t depth, const HitRec& h, ShadowReq& req) {
+    const SceneView& sc = c.sc; const FrameView& fv = c.fv;
+    req.want = false; req.add_now = false; req.contrib = splat3(0.0f); req.dark = splat3(0.0f);
+    req.o = splat3(0.0f); req.d = splat3(0.0f); req.tmin = 0.0f; req.tmax = 0.0f;
+    s.alive = false;
+    if (h.tri == 0xFFFFFFFFu) return;
+    const f3 origin = bounce_origin(s);
+    const f3 next_dir = s.next_dir;
+    HitGeom g = fetch_hit_geometry(sc, h);
+    Surf hit;
+    hit.normal = g.normal_w; hit.uv = g.uv; hit.front_face = h.front;
+    hit.ffnormal = h.front ? g.normal_w : -g.normal_w;
+    hit.t = h.t; hit.pos = origin + next_dir * h.t; hit.mat_id = g.mat_id; hit.tangent = mk4(0, 0, 0, 0);
+    if (depth == 1u) s.v1_pos = hit.pos;
+    f3 wo = -next_dir;
+    const MaterialView& mb = sc.materials[hit.mat_id];
+    MatParams m;
+    m.roughness = mb.roughness; m.metallic = mb.metallic; m.transmission = mb.transmission; m.ior = mb.ior;
+    int32_t light_index_b = mb.light_index;
+    uint32_t t0i = mb.tex_info_0, t1i = mb.tex_info_1;
+    f4 tex_color = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    uint32_t tex_id = t0i & 0xFFFFu, normal_tex_id = t0i >> 16u;
+    if (tex_id != 65535u) tex_color = sample_layer<true>(sc, tex_id, hit.uv);
+    float occlusion = 1.0f;
+    uint32_t occlusion_tex_id = t1i & 0xFFFFu, emissive_tex_id_b = t1i >> 16u;
+    if (occlusion_tex_id != 65535u) occlusion = sample_layer<false>(sc, occlusion_tex_id, hit.uv).x;
+    f3 base_color = mk3(mb.base_color[0], mb.base_color[1], mb.base_color[2]) * xyz(tex_color) * occlusion;
+    if (normal_tex_id != 65535u) {
+        f3 nm = xyz(sample_layer<false>(sc, normal_tex_id, hit.uv));
+        f4 tg = hit_tangent(sc, g);
+        hit.ffnormal = perturb_normal(hit.ffnormal, xyz(tg), tg.w, nm);
+    }
+    s.pos = hit.pos; s.ffnormal = hit.ffnormal;
+    if (light_index_b == -1 && emissive_tex_id_b != 65535u) {   // :675-678
+        f3 emissive_col = xyz(sample_layer<true>(sc, emissive_tex_id_b, hit.uv));
+        s.accumulated = s.accumulated + emissive_col * s.throughput;
+    }
+    if (light_index_b >= 0) {   // :683-700
+        if (hit.front_face) {
+            const LightView& light = sc.lights[light_index_b];
+            f3 Le = mk3(light.emission[0], light.emission[1], light.emission[2]) * light.emission[3];
+            float mis_weight = 1.0f;
+            if (s.previous_was_diffuse) {
+                float dist_sq = hit.t * hit.t;
+                float light_cos = fmaxn(dot(hit.ffnormal, -wo), 0.0f);
+                float p_bsdf = s.last_bsdf_pdf;
+                float p_nee = (1.0f / light.area) * (dist_sq / light_cos) * (1.0f / (float)fv.cam.num_lights);
+                if (light_cos > 0.001f) mis_weight = p_bsdf / (p_bsdf + p_nee);
+                else mis_weight = 0.0f;
+            }
+            s.accumulated = s.accumulated + Le * s.throughput * mis_weight;
+        }
+        return;
+    }
+    if (!(s.is_glass || m.roughness < 0.05f)) {   // :705 — the PRIMARY hit's is_glass (reference quirk)
+        nee_request<VARIANT>(c, hit, wo, m, base_color, s.throughput, req);
+        s.previous_was_diffuse = true;
+    } else s.previous_was_diffuse = false;
+    BsdfSmp sb = sample_bsdf(c, wo, hit.ffnormal, hit.front_face, m, base_color);
+    if (sb.weight.x <= 0.0f && sb.weight.y <= 0.0f && sb.weight.z <= 0.0f) return;
+    s.last_bsdf_pdf = sb.pdf;
+    s.throughput = s.throughput * sb.weight;
+    s.next_dir = sb.wi;
+    const uint32_t next = depth + 1u;
+    if (next >= fv.max_depth) return;
+    if (next >= 3u) {
+        float p = fmaxn(s.throughput.x, fmaxn(s.throughput.y, s.throughput.z));
+        float survival_prob = clampf(p, 0.05f, 0.95f);
+        if (c.rand() > survival_prob) return;
+        s.throughput = s.throughput / survival_prob;
+    }
+    s.alive = true;
+}
+// path_loop in the pulled-apart form, one lane at a time (tests/hostcheck: must equal path_loop bit for bit).
+template <int VARIANT, class Ctx>
+FRT_HD void path_loop_split(Ctx& c, LoopState& s, uint32_t depth_begin, uint32_t depth_end) {
+    bool alive = true;
+    for (uint32_t depth = depth_begin; depth < depth_end && alive; depth++) {
+        HitRec h;
+        c.closest(bounce_origin(s), s.next_dir, 0.001f, 100.0f, h);
+        ShadowReq req;
+        bounce_shade<VARIANT>(c, s, depth, h, req);
+        bool lit = req.add_now;
+        if (req.want) lit = !c.any(req.o, req.d, req.tmin, req.tmax);
+        s.accumulated = s.accumulated + (lit ? req.contrib : req.dark);
+        alive = s.alive;
+    }
+    s.alive = alive;
+}
+
 // ---- continuation records: a LoopState parked in HBM between two launches -------------------------------------------------
 // SoA over slots: word k of slot i lives at words[k * capacity + i], so a wave parking / fetching consecutive slots moves full
 // 256-byte rows per word. 22 words (88 B) per path; the spatial stage adds its merged reservoir (8 words).

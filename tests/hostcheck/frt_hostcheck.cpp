@@ -39,7 +39,7 @@ static void finish_on_host(PathCtx& c, const FrameView& fv, uint32_t pix, const 
     } else spatial_tail(c, pix, r, s.accumulated, s.v1_pos);
 }
 template <int STAGE>
-static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned long long rc[2], bool split) {
+static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned long long rc[2], bool split, bool pulled_apart = false) {
     const uint32_t npix = h->W * h->H;
     std::vector<uint32_t> wa((size_t)kContWordsSpatial * npix), wb((size_t)kContWordsSpatial * npix);
     uint32_t ca = 0, cb = 0;
@@ -73,7 +73,7 @@ static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned lo
             PathCtx c(h->sv, fv, stack, 1u);
             LoopState s; ReservoirView r = zero_reservoir(); uint32_t pix; bool owned;
             cont_load(*qin, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
-            path_loop<V>(c, s, d0, d1);
+            if (pulled_apart) path_loop_split<V>(c, s, d0, d1); else path_loop<V>(c, s, d0, d1);
             rc[0] += c.n_closest; rc[1] += c.n_any;
             if (s.alive) { cont_store(*qout, (*qout->count)++, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr); }
             else finish_on_host<STAGE>(c, fv, pix, r, s, split);
@@ -122,6 +122,7 @@ void hc_set_jitter(void* p, float jx, float jy) { HostCheck* h = (HostCheck*)p; 
 // sm == 1: drive the resumable state machine (frt_path.hpp) instead of the straight-line functions (frt_mono.hpp);
 // sm >= 2: straight-line functions cut at bounce depth `sm` with the continuation-queue protocol (run_stage_cut);
 // sm >= 1000: cut at sm - 1000 AND the temporal stage split into T-trace (candidate record) + T-merge, as the default kernels run it
+// sm >= 2000: cut at sm - 2000, split, and every resumed bounce in the pulled-apart form of the stream kernel (path_loop_split)
 void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     HostCheck* h = (HostCheck*)p;
     uint32_t cur = h->frame_count & 1u, prv = cur ^ 1u;
@@ -139,8 +140,8 @@ void hc_render(void* p, const frt_camera_uniform* cam, int sm) {
     for (int stage = 0; stage < 4; ++stage) {
         if (sm >= 2 && (stage == 1 || stage == 2)) {
             unsigned long long r2[2] = {0, 0};
-            const bool split = sm >= 1000; const uint32_t cutd = (uint32_t)(split ? sm - 1000 : sm);
-            if (stage == 1) run_stage_cut<1>(h, fv, cutd, r2, split); else run_stage_cut<2>(h, fv, cutd, r2, false);
+            const bool pulled = sm >= 2000, split = sm >= 1000; const uint32_t cutd = (uint32_t)(pulled ? sm - 2000 : (split ? sm - 1000 : sm));
+            if (stage == 1) run_stage_cut<1>(h, fv, cutd, r2, split, pulled); else run_stage_cut<2>(h, fv, cutd, r2, false, pulled);
             h->rays[0] += r2[0]; h->rays[1] += r2[1];
             continue;
         }

@@ -19,7 +19,8 @@ def compare_all(got_reader, want_reader, frame, ctx=""):
                 raise AssertionError(f"{ctx} frame {frame} {NAMES[b]}[{idx}]: {len(d)} pixels differ, first at {tuple(d[0])}")
 
 
-@pytest.mark.parametrize("sm", [0, 1, 2, 3, 5, 1001, 1003, 1008], ids=["straight", "state_machine", "cut2", "cut3", "cut5", "split_cut1", "split_cut3", "split_uncut"])
+@pytest.mark.parametrize("sm", [0, 1, 2, 3, 5, 1001, 1003, 1008, 2001, 2003],
+                         ids=["straight", "state_machine", "cut2", "cut3", "cut5", "split_cut1", "split_cut3", "split_uncut", "stream_cut1", "stream_cut3"])
 @pytest.mark.parametrize("which,size,depth,frames,bvh", [("cornell", 64, 8, 4, True), ("cornell", 128, 1, 2, False),
                                                          ("cornell", 48, 16, 2, True), ("restir", 48, 8, 3, True)])
 def test_stage_functions_match_oracle(frt, orc, hostcheck, which, size, depth, frames, bvh, sm):
