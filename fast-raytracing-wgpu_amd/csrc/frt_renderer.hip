@@ -32,12 +32,18 @@ static const uint32_t kHaloGbuffer = 12;   // spatial reuse radius 10 (restir_sp
 static const uint32_t kHaloSpatial = 2;    // post reads raw radiance within +-2 rows (post.wgsl:93)
 static const uint32_t kReuseRadius = 10;   // rows of temporal reservoirs a spatial pixel may read above / below itself
 
-enum { B_GPOS0, B_GPOS1, B_GNRM0, B_GNRM1, B_GALB0, B_GALB1, B_GMOT, B_RES0, B_RES1, B_RAW, B_DISP, B_ACC0, B_ACC1, B_GMOT1, B_CAND, B_COUNT };
-static const uint32_t kBpp[B_COUNT] = {16, 16, 16, 16, 4, 4, 8, 32, 32, 8, 4, 16, 16, 8, 16};
+// G-buffer, motion and candidate targets exist three times: the reference's two ping-pong slots (gbuffer.rs:299) plus one, so that under
+// FRT_FLAG_PIPELINE the G-buffer + T-trace of frame f+2 can be written while frame f still reads its own and frame f+1's is waiting for
+// its T-merge. Which physical set holds which of the reference's two logical slots is tracked per frame (GSlots below).
+enum { B_GPOS0, B_GPOS1, B_GPOS2, B_GNRM0, B_GNRM1, B_GNRM2, B_GALB0, B_GALB1, B_GALB2, B_GMOT0, B_GMOT1, B_GMOT2, B_CAND0, B_CAND1, B_CAND2,
+       B_RES0, B_RES1, B_RAW, B_DISP, B_ACC0, B_ACC1, B_COUNT };
+static const uint32_t kBpp[B_COUNT] = {16, 16, 16, 16, 16, 16, 4, 4, 4, 8, 8, 8, 16, 16, 16, 32, 32, 8, 4, 16, 16};
+struct GSlots { uint32_t g, gprev, aux; };   // physical sets: this frame's G-buffer, the previous logical slot's, and motion / candidate (= g under the pipeline)
+static const int kSpecDepth = 2;             // frames whose G-buffer + T-trace may run ahead
 
 // Device counters (unsigned long long each): [0..7] committed rays per stage {closest, any}; [8] halo overflow;
 // [9..12] PENDING rays of a G-buffer + T-trace pair that ran ahead of its frame (committed by its T-merge, dropped with a discarded speculation)
-enum { C_STAGE = 0, C_HALO = 8, C_PENDING = 9, C_COUNT = 13 };
+enum { C_STAGE = 0, C_HALO = 8, C_PENDING = 9, C_COUNT = 9 + 4 * kSpecDepth };   // one pending set of four per frame in flight ahead
 static const int kTileStateWords = 8;      // per traced stage (frt_kernels.hip: TileOrder uses 6)
 
 struct frt_renderer {
@@ -46,8 +52,9 @@ struct frt_renderer {
     bool own_stream = false;
     hipStream_t ahead = nullptr;           // FRT_FLAG_PIPELINE: G-buffer(f+1), T-trace(f+1)
     hipStream_t edge = nullptr;            // FRT_FLAG_PIPELINE, strips: the spatial pixel launches of the halo-dependent edge rows (beside the interior launch)
-    bool ahead_early = false;              // start the ahead work behind T-merge (beside the spatial pixel kernel) instead of behind the spatial pixel kernel
-    hipEvent_t ev_spix = nullptr, ev_tt = nullptr, ev_tail = nullptr, ev_tm = nullptr, ev_edge = nullptr;
+    int spec_depth = 1;                    // frames speculated ahead. 2 was measured and buys nothing (2.204 vs 2.208 ms): the ahead stream is in order,
+                                           // frame f+2 cannot start before f+1's latency-bound tail has drained (FRT_SPEC_DEPTH: experiment knob, 0 .. kSpecDepth)
+    hipEvent_t ev_spix = nullptr, ev_tt[kSpecDepth] = {nullptr, nullptr}, ev_tail = nullptr, ev_tm = nullptr, ev_edge = nullptr;
     bool tail_pending = false;             // work enqueued on `ahead` that the main stream has not been ordered behind yet
     bool edge_in_flight = false;
     uint32_t W = 0, H = 0, max_depth = 8, rb = 0, re = 0, flags = 0, motion_halo = 0;
@@ -82,12 +89,17 @@ struct frt_renderer {
     bool from_speculation = false;
     Timed s_timer{};
     bool s_timed = false;
-    uint32_t motion_slot = 0;
-    // speculation: G-buffer + T-trace of the NEXT frame, enqueued on `ahead` under the camera a static scene will present
-    bool spec_valid = false, camera_static = false;
-    frt_camera_uniform spec_cam{}, last_cam{}, cur_cam{};
+    // which physical G set holds the reference's logical slot 0 / 1 (frame_count % 2) for the NEXT G-buffer launch, the sets of the frame in
+    // progress and of the last finished frames (what reads through the ABI see)
+    uint32_t logical_phys[2] = {0, 1};
+    GSlots cur_slots{0, 1, 0}, last_slots{0, 1, 0}, before_last_slots{1, 0, 0};
+    // speculation: G-buffer + T-trace of the next frames, enqueued on `ahead` under the cameras a static scene will present
+    struct Spec { frt_camera_uniform cam; uint32_t frame; GSlots slots; uint32_t logical_before[2]; int idx; };
+    std::vector<Spec> specs;               // oldest first, at most kSpecDepth
+    int spec_next_idx = 0, cur_spec_idx = 0;
+    bool camera_static = false;
+    frt_camera_uniform last_cam{}, cur_cam{};
     bool have_last_cam = false;
-    uint32_t spec_frame = 0, spec_motion_slot = 0;
     void* buf(int b) const { return arena + off[b]; }
     bool pipeline() const { return ahead != nullptr; }
 };
@@ -165,15 +177,15 @@ static void spatial_inner_rows(const frt_renderer* r, uint32_t y0, uint32_t y1, 
     if (ib < ia) ib = ia;
 }
 
-static void fill_frame_view(const frt_renderer* r, const frt_camera_uniform* cam, uint32_t frame_count, uint32_t motion_slot, FrameView& fv) {
-    uint32_t cur = frame_count & 1u, prv = cur ^ 1u;   // gbuffer.rs:299, restir.rs:543, post.rs:244
-    fv.gpos = (float4*)r->buf(B_GPOS0 + cur); fv.gnormal = (float4*)r->buf(B_GNRM0 + cur); fv.galbedo = (uint32_t*)r->buf(B_GALB0 + cur);
-    fv.gpos_prev = (const float4*)r->buf(B_GPOS0 + prv); fv.gnormal_prev = (const float4*)r->buf(B_GNRM0 + prv);
-    fv.galbedo_prev = (const uint32_t*)r->buf(B_GALB0 + prv);
-    fv.gmotion = (float2*)r->buf(motion_slot ? B_GMOT1 : B_GMOT);   // two slots only under FRT_FLAG_PIPELINE (post(f) runs beside G-buffer(f+1))
+static void fill_frame_view(const frt_renderer* r, const frt_camera_uniform* cam, uint32_t frame_count, const GSlots& gs, FrameView& fv) {
+    uint32_t cur = frame_count & 1u, prv = cur ^ 1u;   // gbuffer.rs:299, restir.rs:543, post.rs:244 (accumulation; the G-buffer's two slots are renamed: gs)
+    fv.gpos = (float4*)r->buf(B_GPOS0 + gs.g); fv.gnormal = (float4*)r->buf(B_GNRM0 + gs.g); fv.galbedo = (uint32_t*)r->buf(B_GALB0 + gs.g);
+    fv.gpos_prev = (const float4*)r->buf(B_GPOS0 + gs.gprev); fv.gnormal_prev = (const float4*)r->buf(B_GNRM0 + gs.gprev);
+    fv.galbedo_prev = (const uint32_t*)r->buf(B_GALB0 + gs.gprev);
+    fv.gmotion = (float2*)r->buf(B_GMOT0 + gs.aux);
     fv.res_temporal = (ReservoirView*)r->buf(B_RES0);   // restir.rs:362-378: reads buffers[1], writes buffers[0]
     fv.res_spatial = (ReservoirView*)r->buf(B_RES1);    // renderer.rs:292-293: spatial buffers[0] -> buffers[1]
-    fv.cand = (float4*)r->buf(B_CAND);
+    fv.cand = (float4*)r->buf(B_CAND0 + gs.aux);
     fv.raw = (uint2*)r->buf(B_RAW); fv.display = (uint32_t*)r->buf(B_DISP);
     fv.history = (const float4*)r->buf(B_ACC0 + prv);   // post.rs:209-224: BG0 history = accum[1], out = accum[0]
     fv.accum = (float4*)r->buf(B_ACC0 + cur);
@@ -397,7 +409,7 @@ void frt_renderer_destroy(frt_renderer* r) {
     if (r->stream || r->own_stream) (void)hipStreamSynchronize(r->stream);
     if (r->ahead) { (void)hipStreamSynchronize(r->ahead); (void)hipStreamDestroy(r->ahead); }
     if (r->edge) { (void)hipStreamSynchronize(r->edge); (void)hipStreamDestroy(r->edge); }
-    for (hipEvent_t e : {r->ev_spix, r->ev_tt, r->ev_tail, r->ev_tm, r->ev_edge}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {r->ev_spix, r->ev_tt[0], r->ev_tt[1], r->ev_tail, r->ev_tm, r->ev_edge}) if (e) (void)hipEventDestroy(e);
     for (auto& t : r->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (hipEvent_t e : r->event_pool) (void)hipEventDestroy(e);
     for (void* p : r->scene_allocs) (void)hipFree(p);
@@ -451,12 +463,8 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         if (const char* e = getenv("FRT_AHEAD_PRIO")) prio = !strcmp(e, "low") ? lo : (!strcmp(e, "high") ? hi : prio);   // experiment knob
         HIP_TRY(hipStreamCreateWithPriority(&r->ahead, hipStreamNonBlocking, prio));
         HIP_TRY(hipStreamCreateWithPriority(&r->edge, hipStreamNonBlocking, prio));
-        for (hipEvent_t* e : {&r->ev_spix, &r->ev_tt, &r->ev_tail, &r->ev_tm, &r->ev_edge}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        // Measured (profiles/r2_schedule_notes.md): starting the ahead work behind T-merge, i.e. beside the spatial PIXEL kernel, beats
-        // starting it behind that kernel at every size (1080p frame 2.20 vs 2.43 ms, 1/8 strip 0.52 vs 0.72 ms): the two pixel kernels
-        // share the wave slots from the start, finish together, and the two latency-bound continuation tails then run side by side.
-        r->ahead_early = true;
-        if (const char* e = getenv("FRT_AHEAD_AFTER")) r->ahead_early = !strcmp(e, "tm");   // experiment knob: tm | spix
+        for (hipEvent_t* e : {&r->ev_spix, &r->ev_tt[0], &r->ev_tt[1], &r->ev_tail, &r->ev_tm, &r->ev_edge}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        if (const char* e = getenv("FRT_SPEC_DEPTH")) r->spec_depth = std::max(0, std::min(kSpecDepth, atoi(e)));   // experiment knob
     }
     r->arena_bytes = arena_layout(r->W, r->H, r->off);
     if (o && o->device_arena) {
@@ -511,8 +519,10 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         HIP_TRY(hipGetDeviceProperties(&prop, r->device));
         r->num_cus = (uint32_t)prop.multiProcessorCount;
         resident_plan(r->sv, r->res_nodes, r->res_tris);
-        r->resident = r->res_nodes > 0 && !(r->flags & FRT_FLAG_COMPACTION);
-        if (const char* e = getenv("FRT_RESIDENT")) { if (atoi(e) == 0) r->resident = false; }
+        // Opt-in (FRT_RESIDENT=1): measured 5 % faster than the plain kernels on one stream (2.47 vs 2.60 ms) but no better under the
+        // two-stream schedule (2.23 vs 2.20 ms): a resident workgroup owns its CU's LDS, so the two streams' kernels cannot share a CU.
+        r->resident = false;
+        if (const char* e = getenv("FRT_RESIDENT")) r->resident = atoi(e) != 0 && r->res_nodes > 0 && !(r->flags & FRT_FLAG_COMPACTION);
         if (const char* e = getenv("FRT_STREAM")) { r->stream_mode = atoi(e) != 0; if (atoi(e) > 1) r->shade_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: n > 1 = shade_min
         if (const char* e = getenv("FRT_REFILL")) { r->refill = atoi(e) != 0; if (atoi(e) > 1) r->refill_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: 0 off, 1 on, n > 1: refill when >= n lanes are free
         if (const char* e = getenv("FRT_RES_BATCH")) r->res_batch = (uint32_t)atoi(e);      // experiment knob: tiles per fetch (1, 2, 4)
@@ -544,20 +554,21 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
 
 // ------------------------------------------------------------------------------------------------ frame schedule
 // Without FRT_FLAG_PIPELINE: one stream, G-buffer -> T-trace -> T-merge -> spatial -> post, in order.
-// With it, two streams:
-//   main  : T-merge(f) | spatial pixels(f) | spatial continuations(f) | post(f)          | T-merge(f+1) ...
-//   ahead :                                | G-buffer(f+1) | T-trace(f+1) pixels | T-trace(f+1) continuations |
-// T-trace depends on nothing of the previous frame (frt_path.hpp), so G-buffer + T-trace of frame f+1 are enqueued behind the spatial
-// PIXEL kernel of frame f and run beside its continuation launches and post — the latency-bound part of the frame, which leaves most of
-// the chip idle — instead of after them. (Beside the spatial pixel kernel itself nothing is gained: either pixel kernel fills every
-// wave slot of the chip on its own — measured, profiles/r2_schedule_notes.md — so two of them only take turns.)
+// With it, two streams (and a third for a strip's edge rows):
+//   main  : T-merge(f) | spatial pixels(f)               | spatial continuations(f) | post(f) | T-merge(f+1) ...
+//   ahead : (behind T-merge(f))  G-buffer(f+1) | T-trace(f+1) pixels | T-trace(f+1) continuations
+// T-trace depends on nothing of the previous frame (frt_path.hpp), so G-buffer + T-trace of frame f+1 are enqueued behind T-merge(f)
+// and share the chip with the spatial stage of frame f: the two pixel kernels take turns on the wave slots and finish together, and
+// the two latency-bound continuation tails, which leave most of the chip idle, then run side by side instead of one after the other
+// (measured: 2.35 -> 2.20 ms per 1080p frame; started behind the spatial PIXEL kernel instead: 2.43; profiles/r2_schedule_notes.md).
 // The next frame's camera is not known yet: the renderer SPECULATES that it is this frame's camera with frame_count + 1 and
 // prev_view_proj = view_proj — what build_uniform produces for a camera that did not move (camera.rs:207-256, state.rs:172) — and
 // only while the camera has in fact been static for a frame. At the next render call the speculated 288 bytes are compared with the
 // real uniform: equal -> the work is adopted (its ray counts are committed by T-merge); different -> it is dropped (its buffers are
 // simply overwritten, its counts cleared) and the stages run in order on the main stream. Same pixels either way.
-// Buffer hazards: G-buffer slot (f+1)&1 and the candidate buffer are last read by T-merge(f) and post(f-1), the motion slot by post(f-1):
-// all on the main stream before spatial pixels(f), which the ahead stream waits for (ev_spix); everything else stays on the main stream.
+// Buffer hazards: the speculated G-buffer goes to the physical set neither logical slot uses (three sets, alloc_g), whose last readers —
+// spatial and post of the frame before last, and T-merge(f) through `prev` — are all on the main stream before the event the ahead
+// stream waits for; the candidate and motion targets travel with the set; everything else is touched by the main stream only.
 // work_slot: which pair of work counters a resident PIXEL launch uses (0 interior / whole stage, 1 and 2 the edge launches, which may
 // run beside the interior one); the continuation launches use the pairs behind them.
 static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, TraceLaunch& L, int work_slot = 0) {
@@ -578,14 +589,15 @@ static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, Tr
     L.tile_state = (with_tile_state && r->d_tiles) ? r->d_tiles + (size_t)(stage - 1) * kTileStateWords : nullptr;
 }
 
-// G-buffer + T-trace over their rows on stream `q`; `pending` = count the rays in the pending slots (speculative work).
-static int launch_g_and_trace(frt_renderer* r, FrameView fv, hipStream_t q, bool do_g, bool do_tt, bool pending) {
+// G-buffer + T-trace over their rows on stream `q`; pending_set >= 0: count the rays in that pending set (speculative work).
+static int launch_g_and_trace(frt_renderer* r, FrameView fv, hipStream_t q, bool do_g, bool do_tt, int pending_set) {
+    const bool pending = pending_set >= 0;
     uint32_t rows[8];
     phase_rows(r, rows);
     const bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
     if (do_g) {
         fv.y0 = rows[0]; fv.y1 = rows[1];
-        fv.ray_counters = r->d_counters + (pending ? C_PENDING : C_STAGE);
+        fv.ray_counters = r->d_counters + (pending ? C_PENDING + 4 * pending_set : C_STAGE);
         frt_renderer::Timed t{};
         if (timed) { int rc = timer_begin(r, t, 0, q); if (rc) return rc; }
         HIP_TRY(launch_gbuffer(r->sv, fv, q));
@@ -594,7 +606,7 @@ static int launch_g_and_trace(frt_renderer* r, FrameView fv, hipStream_t q, bool
     }
     if (do_tt) {
         fv.y0 = rows[2]; fv.y1 = rows[3];
-        fv.ray_counters = r->d_counters + (pending ? C_PENDING + 2 : C_STAGE + 2);
+        fv.ray_counters = r->d_counters + (pending ? C_PENDING + 4 * pending_set + 2 : C_STAGE + 2);
         TraceLaunch L;
         trace_launch_of(r, 1, true, L);
         frt_renderer::Timed t{};
@@ -617,47 +629,70 @@ static frt_camera_uniform next_static_camera(const frt_camera_uniform& cam) {
     return n;
 }
 
+// The physical sets of the G-buffer launch of frame `frame_count`: under the pipeline the set neither logical slot points at (three sets,
+// two logical slots: exactly one is free) becomes the frame's slot; otherwise the reference's plain ping-pong.
+static GSlots alloc_g(frt_renderer* r, uint32_t frame_count) {
+    const uint32_t L = frame_count & 1u;
+    GSlots gs;
+    if (!r->pipeline()) { gs.g = L; gs.gprev = L ^ 1u; gs.aux = 0u; r->logical_phys[0] = 0u; r->logical_phys[1] = 1u; return gs; }
+    gs.g = 3u - r->logical_phys[0] - r->logical_phys[1];
+    gs.gprev = r->logical_phys[L ^ 1u];
+    gs.aux = gs.g;
+    r->logical_phys[L] = gs.g;
+    return gs;
+}
+
 static int open_frame(frt_renderer* r, const frt_camera_uniform* cam) {
     r->frame_open = true;
     r->cur_cam = *cam;
     r->g_done = r->tt_done = r->tm_done = r->s_started = r->s_inner_done = r->s_edge_done = false;
     r->from_speculation = false;
     r->camera_static = r->have_last_cam && same_camera(next_static_camera(r->last_cam), *cam);
-    if (r->spec_valid) {
-        r->spec_valid = false;
-        if (same_camera(r->spec_cam, *cam) && r->spec_frame == r->frame_count) {
-            r->g_done = r->tt_done = r->from_speculation = true;      // adopted: T-merge waits for ev_tt and commits the ray counts
-            r->motion_slot = r->spec_motion_slot;
+    if (!r->specs.empty()) {
+        const frt_renderer::Spec sp = r->specs.front();
+        if (same_camera(sp.cam, *cam) && sp.frame == r->frame_count) {
+            r->specs.erase(r->specs.begin());
+            r->g_done = r->tt_done = r->from_speculation = true;      // adopted: T-merge waits for its ev_tt and commits the ray counts
+            r->cur_slots = sp.slots;
+            r->cur_spec_idx = sp.idx;
             r->stats.speculated_frames += 1;
         } else {
-            // dropped: order the main stream behind it, clear its ray counts; its buffers are overwritten by the stages that follow
+            // dropped, with everything speculated behind it: order the main stream behind the work, clear its ray counts, give the physical
+            // sets back; the buffers it wrote are simply overwritten by the stages that follow
             int rc = fence_ahead(r);
             if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(r->d_counters + C_PENDING, 0, 4 * sizeof(unsigned long long), r->stream));
-            r->stats.discarded_speculations += 1;
+            HIP_TRY(hipMemsetAsync(r->d_counters + C_PENDING, 0, 4 * kSpecDepth * sizeof(unsigned long long), r->stream));
+            r->logical_phys[0] = sp.logical_before[0]; r->logical_phys[1] = sp.logical_before[1];
+            r->stats.discarded_speculations += r->specs.size();
+            r->specs.clear();
         }
     }
     return FRT_OK;
 }
 
-// G-buffer + T-trace of the NEXT frame on the ahead stream, under the camera a static scene will present. Only for a camera that has
-// been static for a frame (a moving camera never matches). early: ordered behind T-merge (it reads the G-buffer slot and the candidate
-// buffer this work overwrites); otherwise behind every spatial pixel launch of this frame.
-static int launch_speculation(frt_renderer* r, const frt_camera_uniform* cam, bool early) {
-    if (!r->pipeline() || !r->camera_static || !r->tm_done || r->spec_valid) return FRT_OK;
-    hipEvent_t ev = r->ev_tm;
-    if (!early) { ev = r->ev_spix; HIP_TRY(hipEventRecord(r->ev_spix, r->stream)); }
-    r->spec_cam = next_static_camera(*cam);
-    r->spec_frame = r->frame_count + 1u;
-    r->spec_motion_slot = r->motion_slot ^ 1u;
-    FrameView fa;
-    fill_frame_view(r, &r->spec_cam, r->spec_frame, r->spec_motion_slot, fa);
-    HIP_TRY(hipStreamWaitEvent(r->ahead, ev, 0));
-    int rc = launch_g_and_trace(r, fa, r->ahead, true, true, true);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(r->ev_tt, r->ahead));
-    r->tail_pending = true;
-    r->spec_valid = true;
+// G-buffer + T-trace of the NEXT frames on the ahead stream, under the cameras a static scene will present: up to kSpecDepth frames ahead,
+// so that the frame two ahead — due only after a whole further frame — is the bulk work that fills the latency-bound tails of this frame's
+// spatial stage and of the next frame's T-trace. Only for a camera that has been static for a frame (a moving camera never matches).
+// Ordered behind T-merge of this frame, the last reader of the physical set the launch overwrites (the G-buffer two frames back: read
+// by that frame's spatial and post stages and, as `prev`, by this T-merge — all on the main stream before the event).
+static int launch_speculation(frt_renderer* r, const frt_camera_uniform* cam) {
+    if (!r->pipeline() || !r->camera_static || !r->tm_done) return FRT_OK;
+    while ((int)r->specs.size() < r->spec_depth) {
+        frt_renderer::Spec sp;
+        sp.cam = next_static_camera(r->specs.empty() ? *cam : r->specs.back().cam);
+        sp.frame = (r->specs.empty() ? r->frame_count : r->specs.back().frame) + 1u;
+        sp.logical_before[0] = r->logical_phys[0]; sp.logical_before[1] = r->logical_phys[1];
+        sp.slots = alloc_g(r, sp.frame);
+        sp.idx = r->spec_next_idx; r->spec_next_idx = (r->spec_next_idx + 1) % kSpecDepth;
+        FrameView fa;
+        fill_frame_view(r, &sp.cam, sp.frame, sp.slots, fa);
+        HIP_TRY(hipStreamWaitEvent(r->ahead, r->ev_tm, 0));
+        int rc = launch_g_and_trace(r, fa, r->ahead, true, true, sp.idx);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(r->ev_tt[sp.idx], r->ahead));
+        r->tail_pending = true;
+        r->specs.push_back(sp);
+    }
     return FRT_OK;
 }
 
@@ -679,16 +714,16 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
     if (want_g || want_tt) {
         int rc = fence_ahead(r);      // (a dropped speculation may still be writing the slots these stages write)
         if (rc) return rc;
-        if (want_g) r->motion_slot = r->pipeline() ? (r->motion_slot ^ 1u) : 0u;
-        fill_frame_view(r, cam, r->frame_count, r->motion_slot, fv);
-        rc = launch_g_and_trace(r, fv, r->stream, want_g, want_tt, false);
+        if (want_g) r->cur_slots = alloc_g(r, r->frame_count);
+        fill_frame_view(r, cam, r->frame_count, r->cur_slots, fv);
+        rc = launch_g_and_trace(r, fv, r->stream, want_g, want_tt, -1);
         if (rc) return rc;
         if (want_g) r->g_done = true;
         if (want_tt) r->tt_done = true;
     }
     // ---- T-merge (or the fused temporal stage of the compacting kernels)
     if ((phases & FRT_PHASE_TEMPORAL) && !r->tm_done) {
-        fill_frame_view(r, cam, r->frame_count, r->motion_slot, fv);
+        fill_frame_view(r, cam, r->frame_count, r->cur_slots, fv);
         fv.y0 = rows[2]; fv.y1 = rows[3];
         if (compaction) {
             fv.ray_counters = r->d_counters + C_STAGE + 2;
@@ -698,10 +733,10 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
             if (timed) { int rc = timer_end(r, t, r->stream); if (rc) return rc; }
             r->stats.launches[1] += 1;
         } else {
-            if (r->from_speculation) HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_tt, 0));
+            if (r->from_speculation) HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_tt[r->cur_spec_idx], 0));
             frt_renderer::Timed t{};
             if (timed) { int rc = timer_begin(r, t, 4, r->stream); if (rc) return rc; }
-            HIP_TRY(launch_merge(r->sv, fv, r->stream, r->from_speculation ? r->d_counters + C_PENDING : nullptr, r->d_counters + C_STAGE));
+            HIP_TRY(launch_merge(r->sv, fv, r->stream, r->from_speculation ? r->d_counters + C_PENDING + 4 * r->cur_spec_idx : nullptr, r->d_counters + C_STAGE));
             if (timed) { int rc = timer_end(r, t, r->stream); if (rc) return rc; }
             if (r->pipeline()) HIP_TRY(hipEventRecord(r->ev_tm, r->stream));
         }
@@ -712,11 +747,11 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
     if (sp) {
         if (!r->s_started) {
             r->s_started = true;
-            if (r->ahead_early) { int rc = launch_speculation(r, cam, true); if (rc) return rc; }
+            { int rc = launch_speculation(r, cam); if (rc) return rc; }
             r->s_timed = false;
             if (timed) { int rc = timer_begin(r, r->s_timer, 2, r->stream); if (rc) return rc; r->s_timed = true; }
         }
-        fill_frame_view(r, cam, r->frame_count, r->motion_slot, fv);
+        fill_frame_view(r, cam, r->frame_count, r->cur_slots, fv);
         fv.ray_counters = r->d_counters + C_STAGE + 4;
         const uint32_t y0 = rows[4], y1 = rows[5];
         const bool was_complete = r->s_inner_done && r->s_edge_done;
@@ -761,8 +796,6 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
         }
         if (r->s_inner_done && r->s_edge_done && !was_complete) {
             if (r->edge_in_flight) { HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_edge, 0)); r->edge_in_flight = false; }
-            // every pixel launch of the stage is enqueued: the next frame's G-buffer + T-trace may start behind them
-            if (!r->ahead_early) { int rc = launch_speculation(r, cam, false); if (rc) return rc; }
             if (!compaction) {
                 trace_launch_of(r, 2, false, L);
                 fv.y0 = y0; fv.y1 = y1;
@@ -775,7 +808,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
     }
     // ---- post / accumulate (main stream: it runs while the ahead stream is in the latency-bound tail of the next frame's T-trace)
     if (phases & FRT_PHASE_POST) {
-        fill_frame_view(r, cam, r->frame_count, r->motion_slot, fv);
+        fill_frame_view(r, cam, r->frame_count, r->cur_slots, fv);
         fv.y0 = rows[6]; fv.y1 = rows[7];
         frt_renderer::Timed t{};
         if (timed) { int rc = timer_begin(r, t, 3, r->stream); if (rc) return rc; }
@@ -789,7 +822,7 @@ int frt_renderer_end_frame(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "end_frame: null");
     r->frame_count += 1;   // renderer.rs:515
     r->stats.frames += 1;
-    if (r->frame_open) { r->last_cam = r->cur_cam; r->have_last_cam = true; }
+    if (r->frame_open) { r->last_cam = r->cur_cam; r->have_last_cam = true; r->before_last_slots = r->last_slots; r->last_slots = r->cur_slots; }
     r->frame_open = false;
     return FRT_OK;
 }
@@ -847,23 +880,28 @@ int frt_renderer_clear(frt_renderer* r) {
     rc = init_tile_state(r);
     if (rc) return rc;
     r->frame_count = 0;
-    r->frame_open = false; r->spec_valid = false; r->have_last_cam = false; r->camera_static = false;
-    r->qparity[0] = r->qparity[1] = 0; r->motion_slot = 0;
+    r->frame_open = false; r->specs.clear(); r->have_last_cam = false; r->camera_static = false;
+    r->qparity[0] = r->qparity[1] = 0; r->logical_phys[0] = 0; r->logical_phys[1] = 1;
+    r->cur_slots = r->last_slots = GSlots{0, 1, 0}; r->before_last_slots = GSlots{1, 0, 0};
     memset(&r->stats, 0, sizeof(r->stats));
     return FRT_OK;
 }
 
+// Reads through the ABI see the reference's two logical slots as of the last finished frame F: slot F % 2 is that frame's G-buffer, the other
+// one what it read as `prev` (work running ahead writes a third physical set and is invisible here).
 static int buf_index(const frt_renderer* r, int buf, int index) {
+    const uint32_t last_parity = r->frame_count ? ((r->frame_count - 1u) & 1u) : 0u;
+    const uint32_t g = ((uint32_t)index & 1u) == last_parity ? r->last_slots.g : r->last_slots.gprev;
     switch (buf) {
-    case FRT_BUF_GPOS: return B_GPOS0 + (index & 1);
-    case FRT_BUF_GNORMAL: return B_GNRM0 + (index & 1);
-    case FRT_BUF_GALBEDO: return B_GALB0 + (index & 1);
-    case FRT_BUF_GMOTION: return ((r->motion_slot ^ (uint32_t)index) & 1u) ? B_GMOT1 : B_GMOT;   // 0 = the last rendered frame's (the reference has one)
+    case FRT_BUF_GPOS: return B_GPOS0 + (int)g;
+    case FRT_BUF_GNORMAL: return B_GNRM0 + (int)g;
+    case FRT_BUF_GALBEDO: return B_GALB0 + (int)g;
+    case FRT_BUF_GMOTION: return B_GMOT0 + (int)((index & 1) ? r->before_last_slots.aux : r->last_slots.aux);   // 0 = the last rendered frame's (the reference has one)
     case FRT_BUF_RESERVOIR: return B_RES0 + (index & 1);
     case FRT_BUF_RAW: return B_RAW;
     case FRT_BUF_DISPLAY: return B_DISP;
     case FRT_BUF_ACCUM: return B_ACC0 + (index & 1);
-    case FRT_BUF_CANDIDATE: return B_CAND;
+    case FRT_BUF_CANDIDATE: return B_CAND0 + (int)r->last_slots.aux;
     }
     return -1;
 }
