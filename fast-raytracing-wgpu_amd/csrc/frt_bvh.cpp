@@ -154,7 +154,7 @@ static void quantize_pair_nodes(SceneBuilder& b) {
         for (int c = 0; c < 2; ++c) {
             uint32_t ref; memcpy(&ref, &p.q[12 + c], 4);
             if (ref == kNoChild) continue;
-            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)p.q[6 * c + a]); hi[a] = std::max(hi[a], (double)p.q[6 * c + 3 + a]); }
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)p.q[4 * a + c]); hi[a] = std::max(hi[a], (double)p.q[4 * a + 2 + c]); }
         }
     for (int a = 0; a < 3; ++a) {
         if (!(hi[a] > lo[a])) { hi[a] = lo[a] + 1e-3; }
@@ -171,7 +171,7 @@ static void quantize_pair_nodes(SceneBuilder& b) {
             uint32_t l[3], h[3];
             for (int a = 0; a < 3; ++a) {
                 if (ref == kNoChild) { l[a] = 65535u; h[a] = 0u; }
-                else { l[a] = q_lo(p.q[6 * c + a], a); h[a] = q_hi(p.q[6 * c + 3 + a], a); }
+                else { l[a] = q_lo(p.q[4 * a + c], a); h[a] = q_hi(p.q[4 * a + 2 + c], a); }
             }
             uint32_t* w = (c == 0 ? b.qnode_a.data() : b.qnode_b.data()) + 4 * i;
             w[0] = l[0] | (l[1] << 16); w[1] = l[2] | (h[0] << 16); w[2] = h[1] | (h[2] << 16); w[3] = ref;
@@ -219,8 +219,8 @@ void SceneBuilder::build_gpu_layout() {
             lo[a] = n ? n->bmin[a] : std::numeric_limits<float>::infinity();
             hi[a] = n ? n->bmax[a] : -std::numeric_limits<float>::infinity();
         }
-        if (child == 0) { p.q[0] = lo[0]; p.q[1] = lo[1]; p.q[2] = lo[2]; p.q[3] = hi[0]; p.q[4] = hi[1]; p.q[5] = hi[2]; }
-        else { p.q[6] = lo[0]; p.q[7] = lo[1]; p.q[8] = lo[2]; p.q[9] = hi[0]; p.q[10] = hi[1]; p.q[11] = hi[2]; }
+        // one float4 per axis: (lo of child 0, lo of child 1, hi of child 0, hi of child 1) — frt_trace.hpp: slab2
+        for (int a = 0; a < 3; ++a) { p.q[4 * a + child] = lo[a]; p.q[4 * a + 2 + child] = hi[a]; }
     };
     auto put_ref = [](PairNode& p, int child, uint32_t ref) { memcpy(&p.q[12 + child], &ref, 4); };
     if (order.empty()) {

@@ -442,10 +442,7 @@ __device__ __forceinline__ void lane_ray_begin(LaneRay& tr, f3 o, f3 d, float tm
 // the same visiting order per ray as trace() (frt_trace.hpp): the closest hit and the any-hit answer are the ones trace() finds.
 __device__ __forceinline__ void traverse_round(const SceneView& sc, LaneRay& tr, bool go, bool any_hit, uint32_t* stk, uint32_t stride) {
     const uint32_t kDone = 0xFFFFFFFFu;
-    const float kTiny = 8.271806125530277e-25f;
-    f3 inv = mk3(1.0f / (fabsf_(tr.d.x) > kTiny ? tr.d.x : __builtin_copysignf(kTiny, tr.d.x)),
-                 1.0f / (fabsf_(tr.d.y) > kTiny ? tr.d.y : __builtin_copysignf(kTiny, tr.d.y)),
-                 1.0f / (fabsf_(tr.d.z) > kTiny ? tr.d.z : __builtin_copysignf(kTiny, tr.d.z)));
+    f3 inv = mk3(prune_rcp(tr.d.x), prune_rcp(tr.d.y), prune_rcp(tr.d.z));
     f3 oinv = mk3(-tr.o.x * inv.x, -tr.o.y * inv.y, -tr.o.z * inv.z);
 #pragma nounroll
     for (int it = 0; it < kSliceNodes; ++it) {
@@ -456,8 +453,8 @@ __device__ __forceinline__ void traverse_round(const SceneView& sc, LaneRay& tr,
             float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
             float tlim = any_hit ? tr.tmax : tr.t;
             float t0, t1;
-            bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, inv, oinv, tr.tmin, tlim, t0);
-            bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, inv, oinv, tr.tmin, tlim, t1);
+            bool h0, h1;
+            slab2(q0, q1, q2, inv, oinv, tr.tmin, tlim, t0, t1, h0, h1);
             uint32_t r0 = f2u(q3.x), r1 = f2u(q3.y);
             h0 = h0 && (r0 != kDone);
             h1 = h1 && (r1 != kDone);

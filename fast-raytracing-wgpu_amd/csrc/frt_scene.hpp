@@ -59,7 +59,8 @@ struct TriRec { float v0[3], e1[3], e2[3]; };
 
 // GPU layouts -------------------------------------------------------------------------------------------
 // Pair node, 64 B: the boxes of both children of one BVH2 inner node + two child references.
-//   q0 = (c0.min.xyz, c0.max.x)  q1 = (c0.max.yz, c1.min.xy)  q2 = (c1.min.z, c1.max.xyz)  q3 = (ref0, ref1, 0, 0) as bits
+//   one float4 per axis: qa = (c0.min.a, c1.min.a, c0.max.a, c1.max.a) for a = x, y, z (pairs for v_pk_fma_f32, frt_trace.hpp: slab2);
+//   q3 = (ref0, ref1, 0, 0) as bits
 // ref: bit 31 clear -> pair-node index; bit 31 set -> leaf: bits 0..23 first triangle slot, bits 24..30 triangle count.
 // An absent child has ref = 0xFFFFFFFF and an inverted box.
 struct PairNode { float q[16]; };

@@ -83,18 +83,43 @@ FRT_HD bool slab(float lox, float loy, float loz, float hix, float hiy, float hi
     return tn <= tf * 1.0000004f;
 }
 
+// Both child boxes of a pair node at once. Node layout (frt_bvh.cpp: put_box): one float4 per axis = (lo0, lo1, hi0, hi1), so that the
+// six ray-plane distances of an axis pair up as two packed fma (v_pk_fma_f32: two results per issue slot) straight out of the load.
+typedef float frt_v2f __attribute__((ext_vector_type(2)));
+FRT_HD void slab2(float4 qx, float4 qy, float4 qz, f3 inv, f3 oinv, float tmin, float tlim, float& t0, float& t1, bool& h0, bool& h1) {
+    const frt_v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const frt_v2f ox = {oinv.x, oinv.x}, oy = {oinv.y, oinv.y}, oz = {oinv.z, oinv.z};
+    const frt_v2f xl = __builtin_elementwise_fma(frt_v2f{qx.x, qx.y}, ix, ox), xh = __builtin_elementwise_fma(frt_v2f{qx.z, qx.w}, ix, ox);
+    const frt_v2f yl = __builtin_elementwise_fma(frt_v2f{qy.x, qy.y}, iy, oy), yh = __builtin_elementwise_fma(frt_v2f{qy.z, qy.w}, iy, oy);
+    const frt_v2f zl = __builtin_elementwise_fma(frt_v2f{qz.x, qz.y}, iz, oz), zh = __builtin_elementwise_fma(frt_v2f{qz.z, qz.w}, iz, oz);
+    float tn0 = fmaxn(fmaxn(fminn(xl.x, xh.x), fminn(yl.x, yh.x)), fmaxn(fminn(zl.x, zh.x), tmin));
+    float tf0 = fminn(fminn(fmaxn(xl.x, xh.x), fmaxn(yl.x, yh.x)), fminn(fmaxn(zl.x, zh.x), tlim));
+    float tn1 = fmaxn(fmaxn(fminn(xl.y, xh.y), fminn(yl.y, yh.y)), fmaxn(fminn(zl.y, zh.y), tmin));
+    float tf1 = fminn(fminn(fmaxn(xl.y, xh.y), fmaxn(yl.y, yh.y)), fminn(fmaxn(zl.y, zh.y), tlim));
+    t0 = tn0; t1 = tn1;
+    h0 = tn0 <= tf0 * 1.0000004f;
+    h1 = tn1 <= tf1 * 1.0000004f;
+}
+// 1 / d for the box tests with |d| clamped to 2^-80: keeps inv finite so that fma(b, inv, -o*inv) never evaluates inf - inf (a ray lying
+// in an axis plane, d.y == 0, is common here: reconnection rays along a wall). Hardware reciprocal (1 ulp) on the device: pruning only,
+// not contract arithmetic — the boxes are padded and the test has its own slack.
+FRT_HD float prune_rcp(float x) {
+    const float kTiny = 8.271806125530277e-25f;
+    const float c = fabsf_(x) > kTiny ? x : __builtin_copysignf(kTiny, x);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(c);
+#else
+    return 1.0f / c;
+#endif
+}
+
 // ANY = true: terminate on the first accepted hit (shadow / visibility rays); returns hit.tri != miss.
 // `stk` is this lane's traversal stack: kStackDepth entries, `stride` words apart (LDS column on the device).
 template <bool ANY>
 FRT_HD void trace(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint32_t* stk, uint32_t stride, HitRec& hit) {
     hit.t = tmax; hit.tri = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f; hit.inst = 0u; hit.front = false;
     float best_det = 0.0f;
-    // 1/d with |d| clamped to 2^-80: keeps inv finite so that fma(b, inv, -o*inv) never evaluates inf - inf (a ray lying
-    // in an axis plane, d.y == 0, is common here: reconnection rays along a wall). Pruning only; not contract arithmetic.
-    const float kTiny = 8.271806125530277e-25f;
-    f3 inv = mk3(1.0f / (fabsf_(d.x) > kTiny ? d.x : __builtin_copysignf(kTiny, d.x)),
-                 1.0f / (fabsf_(d.y) > kTiny ? d.y : __builtin_copysignf(kTiny, d.y)),
-                 1.0f / (fabsf_(d.z) > kTiny ? d.z : __builtin_copysignf(kTiny, d.z)));
+    f3 inv = mk3(prune_rcp(d.x), prune_rcp(d.y), prune_rcp(d.z));
     f3 oinv = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
     // "while-while" traversal: an inner loop walks pair nodes until THIS lane holds a leaf (lanes that already do wait for
     // the rest of the wave), then the leaf's triangles are tested together (measured 3 % faster than one loop with a branch).
@@ -107,8 +132,8 @@ FRT_HD void trace(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint3
             float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
             float tlim = ANY ? tmax : hit.t;
             float t0, t1;
-            bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, inv, oinv, tmin, tlim, t0);
-            bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, inv, oinv, tmin, tlim, t1);
+            bool h0, h1;
+            slab2(q0, q1, q2, inv, oinv, tmin, tlim, t0, t1, h0, h1);
             uint32_t r0 = f2u(q3.x), r1 = f2u(q3.y);
             h0 = h0 && (r0 != kDone);   // absent child (single-leaf scenes)
             h1 = h1 && (r1 != kDone);
@@ -171,10 +196,7 @@ template <bool ANY, class Bvh>
 FRT_HD void trace_q(const SceneView& sc, const Bvh& bv, f3 o, f3 d, float tmin, float tmax, uint32_t* stk, uint32_t stride, HitRec& hit) {
     hit.t = tmax; hit.tri = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f; hit.inst = 0u; hit.front = false;
     float best_det = 0.0f;
-    const float kTiny = 8.271806125530277e-25f;
-    f3 inv = mk3(1.0f / (fabsf_(d.x) > kTiny ? d.x : __builtin_copysignf(kTiny, d.x)),
-                 1.0f / (fabsf_(d.y) > kTiny ? d.y : __builtin_copysignf(kTiny, d.y)),
-                 1.0f / (fabsf_(d.z) > kTiny ? d.z : __builtin_copysignf(kTiny, d.z)));
+    f3 inv = mk3(prune_rcp(d.x), prune_rcp(d.y), prune_rcp(d.z));
     f3 oinv = mk3((bv.qmin.x - o.x) * inv.x, (bv.qmin.y - o.y) * inv.y, (bv.qmin.z - o.z) * inv.z);
     inv = mk3(inv.x * bv.qstep.x, inv.y * bv.qstep.y, inv.z * bv.qstep.z);
     const uint32_t kDone = 0xFFFFFFFFu;
