@@ -110,6 +110,10 @@ void orc_camera_build(const float pos[3], float yaw, float pitch, const float* p
 }
 void orc_camera_halton_jitter(uint32_t index, uint32_t w, uint32_t h, float scale, float out[2]) { camera_halton_jitter(index, w, h, scale, out); }
 
+// Text mode (orc_math.hpp): process-wide; set it before rendering.
+void orc_set_text_mode(int on) { text_mode() = on != 0; }
+int orc_get_text_mode(void) { return text_mode() ? 1 : 0; }
+
 // ---- tracing probes (T2): closest/any over n rays; o,d are n*3 floats
 void orc_trace_closest(void* sp, int use_bvh, uint32_t n, const float* o, const float* d, float tmin, float tmax,
                        float* t_out, uint32_t* tri_out, float* uv_out, uint8_t* front_out, uint64_t stats[4]) {

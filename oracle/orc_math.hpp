@@ -16,6 +16,14 @@
 
 namespace orc {
 
+// TEXT MODE (tests only): evaluate the WGSL as written, with the C library standing in for the GPU's builtins — true division wherever
+// the shader divides, pow(x, y) = exp2(y * log2(x)) (NaN for a negative base, like WGSL), normalize = v * inverseSqrt(dot(v, v)), libm
+// sin / cos / exp / log2 — instead of the numeric contract below (reciprocal-multiply, pow by repeated multiplication, polynomials),
+// which was chosen so that CPU and GPU agree bit for bit and, in places, because it is cheaper on the GPU. A path tracer is chaotic per
+// pixel, so the two modes cannot be compared pixel by pixel; tests/test_oracle_text_mode.py compares the accumulated images
+// statistically and so bounds what the contract costs relative to a literal reading of the reference. Set before rendering, never during.
+inline bool& text_mode() { static bool on = false; return on; }
+
 struct vec2 { float x, y; };
 struct vec3 { float x, y, z; };
 struct vec4 { float x, y, z, w; };
@@ -41,7 +49,10 @@ inline vec3 operator*(vec3 a, vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}
 inline vec3 operator*(vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 inline vec3 operator*(float s, vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
 // vector / scalar: one IEEE reciprocal, then three multiplies (contract; WGSL allows 2.5 ulp for division)
-inline vec3 operator/(vec3 a, float s) { float r = 1.0f / s; return {a.x * r, a.y * r, a.z * r}; }
+inline vec3 operator/(vec3 a, float s) {
+    if (text_mode()) return {a.x / s, a.y / s, a.z / s};
+    float r = 1.0f / s; return {a.x * r, a.y * r, a.z * r};
+}
 inline vec3 operator/(vec3 a, vec3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
 inline vec3 operator+(vec3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
 inline vec3 operator-(float s, vec3 a) { return {s - a.x, s - a.y, s - a.z}; }
@@ -83,7 +94,10 @@ inline vec3 cross(vec3 a, vec3 b) {
 inline float length(vec3 v) { return sqrtf(dot(v, v)); }
 inline float length2(vec2 v) { return sqrtf(dot2(v, v)); }
 // normalize: v * (1 / length(v)) — one IEEE division, then three multiplies (contract; WGSL leaves it open)
-inline vec3 normalize(vec3 v) { float r = 1.0f / length(v); return v * r; }
+inline vec3 normalize(vec3 v) {
+    if (text_mode()) return v * inversesqrt_(dot(v, v));
+    float r = 1.0f / length(v); return v * r;
+}
 inline float distance(vec3 a, vec3 b) { return length(a - b); }
 inline vec3 reflect(vec3 i, vec3 n) { return i - n * (2.0f * dot(n, i)); }
 inline vec3 refract(vec3 i, vec3 n, float eta) {
@@ -111,6 +125,7 @@ inline uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 // sin/cos: Cody-Waite reduction by pi/2 (3 constants), Cephes sinf/cosf minimax
 // polynomials on [-pi/4, pi/4]. Valid for |x| < ~1e5; the shaders only pass [0, 2*pi].
 inline void sincos_(float x, float* s, float* c) {
+    if (text_mode()) { *s = sinf(x); *c = cosf(x); return; }
     float q = floorf(x * 0.636619772f + 0.5f);
     float r = x - q * 1.5703125f;
     r = r - q * 4.837512969970703125e-4f;
@@ -131,6 +146,7 @@ inline float cos_(float x) { float s, c; sincos_(x, &s, &c); return c; }
 
 // exp2: n = floor(x + 0.5), f = x - n in [-0.5, 0.5], Cephes exp2f polynomial, scale by 2^n.
 inline float exp2_(float x) {
+    if (text_mode()) return exp2f(x);
     if (x >= 128.0f) return bits2f(0x7f800000u);
     if (!(x >= -126.0f)) return 0.0f;   // also NaN -> 0
     float n = floorf(x + 0.5f);
@@ -150,6 +166,7 @@ inline float exp2_(float x) {
 
 // log2 for x > 0 (normal or denormal): x = m * 2^e, m in [sqrt(1/2), sqrt(2)), Cephes log2f polynomial.
 inline float log2_(float x) {
+    if (text_mode()) return log2f(x);
     uint32_t u = f2bits(x);
     int e = 0;
     if ((u & 0x7f800000u) == 0) { x = x * 8388608.0f; u = f2bits(x); e = -23; }
@@ -177,14 +194,18 @@ inline float log2_(float x) {
 }
 
 // pow(x, 5) / pow(x, 20) of the shaders by repeated multiplication (contract), x >= 0 at every call site
-inline float pow5_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x; }
-inline float pow20_(float x) { float x2 = x * x; float x4 = x2 * x2; float x8 = x4 * x4; float x16 = x8 * x8; return x16 * x4; }
+inline float pow5_(float x) { if (text_mode()) return exp2f(5.0f * log2f(x)); float x2 = x * x; float x4 = x2 * x2; return x4 * x; }
+inline float pow20_(float x) {
+    if (text_mode()) return exp2f(20.0f * log2f(x));
+    float x2 = x * x; float x4 = x2 * x2; float x8 = x4 * x4; float x16 = x8 * x8; return x16 * x4;
+}
 // pow(x, y) for the shader uses (y > 0): x <= 0 (or NaN) -> 0.
 inline float pow_(float x, float y) {
+    if (text_mode()) return exp2f(y * log2f(x));
     if (!(x > 0.0f)) return 0.0f;
     return exp2_(y * log2_(x));
 }
-inline float exp_(float x) { return exp2_(x * 1.44269504088896340736f); }
+inline float exp_(float x) { if (text_mode()) return expf(x); return exp2_(x * 1.44269504088896340736f); }
 
 inline vec3 pow3(vec3 v, float y) { return {pow_(v.x, y), pow_(v.y, y), pow_(v.z, y)}; }
 

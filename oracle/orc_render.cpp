@@ -202,7 +202,7 @@ static float eval_pdf(vec3 normal, vec3 wi, vec3 wo, const Material& mat, vec3 b
     float d = ndf_ggx(n_dot_h, mat.roughness);
     float g1 = geometry_schlick_ggx(n_dot_v, mat.roughness);
     float pdf_spec = (d * g1) / (4.0f * n_dot_v);
-    float pdf_diff = fmax_(n_dot_l, 0.0f) * (1.0f / PI);   // x / PI evaluated as x * (1 / PI) (contract)
+    float pdf_diff = text_mode() ? fmax_(n_dot_l, 0.0f) / PI : fmax_(n_dot_l, 0.0f) * (1.0f / PI);   // x / PI evaluated as x * (1 / PI) (contract)
     return prob_spec * pdf_spec + (1.0f - prob_spec) * pdf_diff;
 }
 static vec3 eval_bsdf(vec3 normal, vec3 wi, vec3 wo, const Material& mat, vec3 base_color) {   // :278-305
@@ -775,6 +775,7 @@ static void spatial_pixel(Ctx& c, Renderer& R, uint32_t px, uint32_t py) {
 // ------------------------------------------------------------------ stage 3: post.wgsl:61-282
 static float gauss(float x, float sigma) {   // post.wgsl:21-26
     if (sigma < 0.001f) return fabsf(x) < 0.001f ? 1.0f : 0.0f;
+    if (text_mode()) return exp_(-(x * x) / (2.0f * sigma * sigma));
     return exp_(-(x * x) * (1.0f / (2.0f * sigma * sigma)));   // x / c evaluated as x * (1 / c) (contract)
 }
 static vec3 rgb_to_ycocg(vec3 rgb) {

@@ -1,0 +1,64 @@
+"""RCCL rehearsal on ONE GPU: the N > 1 frame loop of bench.py (frt.dist.render_strip_frame: arena views as send / receive buffers, the "mid"
+exchange posted behind T-merge and finished on the edge-row stream, the "post" exchange a frame ahead) over the real "nccl" backend with a
+world of one rank, every transfer a send-to-self inside one batch. The image means nothing (the strip's "neighbour" is itself); what is
+checked is that the communicator comes up on cuda:0, that device-to-device point-to-point transfers of arena rows complete under the
+stream ordering the loop sets up, and that the rows arrive bit for bit. Prints one JSON line."""
+import json
+import os
+import sys
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fast-raytracing-wgpu_amd"))
+
+
+def main():
+    port = sys.argv[1] if len(sys.argv) > 1 else "29533"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import frt
+    from frt.dist import StripPlan, ArenaRows, render_strip_frame, HALO_RESERVOIR, BUF_RESERVOIR, BUF_ACCUM
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+    class Loopback(StripPlan):
+        """A strip in the middle of the image whose upper AND lower neighbour is this rank: its top boundary rows go to the halo below it."""
+        def __init__(self, H, rb, re):
+            self.H, self.world, self.rank, self.motion_halo = H, 1, 0, 0
+            self.boundaries = [0, H]; self.row_begin, self.row_end = rb, re
+
+        def transfers(self, frame, when="mid"):
+            rb, re = self.row_begin, self.row_end
+            if when == "mid":
+                return [(0, BUF_RESERVOIR, 0, (rb, rb + HALO_RESERVOIR), (re, re + HALO_RESERVOIR))]
+            if when == "post" and frame > 0:
+                return [(0, BUF_ACCUM, (frame - 1) % 2, (rb, rb + 1), (re, re + 1))]
+            return []
+
+    W, H, rb, re = 640, 360, 96, 240
+    scene = frt.scenes.create_cornell_box()
+    nbytes = frt.Renderer.arena_bytes(W, H)
+    arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device="cuda:0")
+    off = (-arena.data_ptr()) % 256
+    r = frt.Renderer(scene, W, H, device=0, stream=torch.cuda.current_stream().cuda_stream, rows=(rb, re),
+                     arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_PIPELINE)
+    rows = ArenaRows(r, arena)
+    plan = Loopback(H, rb, re)
+    ok = True
+    N = 4
+    for f in range(N):
+        render_strip_frame(r, rows, plan, frt.CameraController().build_uniform(W / H, f, 2), f, frt)
+    torch.cuda.synchronize()
+    res = r.read_buffer(frt.BUF_RESERVOIR, 0)
+    ok &= bool(res[rb:rb + HALO_RESERVOIR].any()) and res[re:re + HALO_RESERVOIR].tobytes() == res[rb:rb + HALO_RESERVOIR].tobytes()
+    hist = r.read_buffer(frt.BUF_ACCUM, (N - 2) % 2)       # the slot the last frame's "post" exchange moved a row of
+    ok &= bool(hist[rb].any()) and hist[re].tobytes() == hist[rb].tobytes()
+    st = r.stats()
+    print(json.dumps({"ok": bool(ok), "speculated_frames": st["speculated_frames"], "nccl": True}))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,6 +25,7 @@ class Oracle:
             "orc_scene_set_bvh": (C.c_int, [P, P, U32, P, U32]), "orc_camera_default": (None, [C.c_float, U32, U32, P]),
             "orc_camera_build": (None, [P, C.c_float, C.c_float, P, C.c_float, U32, U32, C.c_float, C.c_float, P, P]),
             "orc_camera_halton_jitter": (None, [U32, U32, U32, C.c_float, P]), "orc_renderer_set_jitter": (None, [P, C.c_float, C.c_float]),
+            "orc_set_text_mode": (None, [C.c_int]), "orc_get_text_mode": (C.c_int, []),
             "orc_trace_closest": (None, [P, C.c_int, U32, P, P, C.c_float, C.c_float, P, P, P, P, P]),
             "orc_trace_any": (None, [P, C.c_int, U32, P, P, C.c_float, P, P]),
             "orc_renderer_create": (P, [P, U32, U32, U32, C.c_int, C.c_int]), "orc_renderer_destroy": (None, [P]),
@@ -37,6 +38,10 @@ class Oracle:
         }
         for n, (r, a) in sig.items():
             f = getattr(L, n); f.restype = r; f.argtypes = a
+
+    def set_text_mode(self, on):
+        """Literal evaluation of the WGSL (true division, pow = exp2(y log2 x), libm) instead of the numeric contract. Process-wide."""
+        self.L.orc_set_text_mode(int(bool(on)))
 
     # ---- scene
     def cornell(self):
@@ -146,6 +151,9 @@ class OrcRenderer:
     @property
     def frame_count(self):
         return self.L.orc_renderer_frame_count(self.h)
+
+    def reset(self):                # zero every buffer and the counter (a fresh renderer)
+        self.L.orc_renderer_reset(self.h)
 
     def restart_counter(self):      # state.rs:152
         self.L.orc_renderer_restart_counter(self.h)

@@ -95,20 +95,25 @@ def test_full_size_properties(gpu, orc):
     # ray budget: <= 36 rays per pixel per frame at MAX_DEPTH 8, and at least the primary ray
     rays = st["rays_closest"] + st["rays_any"]
     assert W * H * N <= rays <= 36 * W * H * N
-    # oracle on a horizontal band (pixels depend only on rows within +-12 of themselves per frame; N frames -> N*12 rows)
+    # oracle on two horizontal bands (pixels depend only on rows within +-12 of themselves per frame; N frames -> N*12 rows): rows 500-520
+    # cross the back wall and the tall box, rows 900-930 the glass crystal with its sphere light, the mirror-like box and the checkered floor — the expensive
+    # and quirky branches (delta glass, refraction, the roughness-0.01 box's overflowing GGX term, textured albedo)
     del r2
-    y0, y1 = 500, 520
-    halo = 12 * N + 2
     os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
-    ro = os_.renderer(W, H, 8, True, 16)
-    for f in range(N):
-        cam = cams[f]
-        a, b = y0 - halo, y1 + halo
-        ro.render_phases(cam, 1, a - 14, b + 14); ro.render_phases(cam, 2, a - 12, b + 12)
-        ro.render_phases(cam, 4, a - 2, b + 2); ro.render_phases(cam, 8, a, b); ro.end_frame()
-        halo -= 12
-    want = ro.read(7, (N - 1) % 2).view(np.float32)[y0:y1]
-    assert np.abs(acc[y0:y1] - want).max() <= TOL and np.array_equal(acc[y0:y1], want)
+    for y0, y1 in ((500, 520), (900, 930)):
+        halo = 12 * N + 2
+        ro = os_.renderer(W, H, 8, True, 16)
+        for f in range(N):
+            cam = cams[f]
+            a, b = y0 - halo, y1 + halo
+            ro.render_phases(cam, 1, a - 14, b + 14); ro.render_phases(cam, 2, a - 12, b + 12)
+            ro.render_phases(cam, 4, a - 2, b + 2); ro.render_phases(cam, 8, a, b); ro.end_frame()
+            halo -= 12
+        want = ro.read(7, (N - 1) % 2).view(np.float32)[y0:y1]
+        assert np.abs(acc[y0:y1] - want).max() <= TOL and np.array_equal(acc[y0:y1], want), (y0, y1)
+        mats = set(np.unique(pos[y0:y1, :, 3]).astype(int).tolist())
+        if y0 == 900:
+            assert {3, 4, 5} <= mats, mats       # the checkered floor (material 3), the roughness-0.01 metal box (4) and the glass crystal (5) are in the band
 
 
 def test_strips_equal_whole_image(gpu):
@@ -400,3 +405,16 @@ def test_jittered_frames_on_gpu(gpu, orc):
     strip.set_jitter((0.01, 0.0))
     with pytest.raises(frt.FrtError):
         strip.render(frt.CameraController().build_uniform(W / H, 0, 2))
+
+
+def test_rccl_loopback_rehearsal_on_one_gpu(gpu):
+    """The real "nccl" (= RCCL) backend with a world of one rank: bench.py's N > 1 frame loop with every halo transfer a device-to-device
+    send-to-self of arena rows (tests/_nccl_selftest.py). An 8-GPU node is not available to the tests; this is as much of the RCCL code
+    path as one GPU can execute, so that the first multi-GPU run is not its first execution."""
+    import json, subprocess, sys
+    from test_dist_gloo import _free_port
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nccl_selftest.py"), str(_free_port())],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["nccl"], res
