@@ -32,14 +32,26 @@ static const uint32_t kHaloGbuffer = 12;   // spatial reuse radius 10 (restir_sp
 static const uint32_t kHaloSpatial = 2;    // post reads raw radiance within +-2 rows (post.wgsl:93)
 static const uint32_t kReuseRadius = 10;   // rows of temporal reservoirs a spatial pixel may read above / below itself
 
-// G-buffer, motion and candidate targets exist three times: the reference's two ping-pong slots (gbuffer.rs:299) plus one, so that under
-// FRT_FLAG_PIPELINE the G-buffer + T-trace of frame f+2 can be written while frame f still reads its own and frame f+1's is waiting for
-// its T-merge. Which physical set holds which of the reference's two logical slots is tracked per frame (GSlots below).
-enum { B_GPOS0, B_GPOS1, B_GPOS2, B_GNRM0, B_GNRM1, B_GNRM2, B_GALB0, B_GALB1, B_GALB2, B_GMOT0, B_GMOT1, B_GMOT2, B_CAND0, B_CAND1, B_CAND2,
-       B_RES0, B_RES1, B_RAW, B_DISP, B_ACC0, B_ACC1, B_COUNT };
-static const uint32_t kBpp[B_COUNT] = {16, 16, 16, 16, 16, 16, 4, 4, 4, 8, 8, 8, 16, 16, 16, 32, 32, 8, 4, 16, 16};
+// G-buffer, motion and candidate targets exist kGSets = kSpecDepth + 1 times. With one frame running ahead (the default) that is the
+// reference's two ping-pong slots (gbuffer.rs:299): G-buffer(f+1) overwrites the set of frame f-1, whose last readers are done by then.
+// Two frames ahead (kSpecDepth = 2, a third set: +60 B per pixel) was built and measured: 2.204 vs 2.208 ms — the ahead stream is in
+// order, so frame f+2 cannot start before f+1's latency-bound tail has drained — and is therefore not compiled in. Which physical set
+// holds which of the reference's two logical slots is tracked per frame (GSlots below), so any kSpecDepth works.
+static const int kSpecDepth = 1;             // frames whose G-buffer + T-trace may run ahead
+static const int kGSets = kSpecDepth + 1;
+enum { B_GPOS0 = 0, B_GNRM0 = B_GPOS0 + kGSets, B_GALB0 = B_GNRM0 + kGSets, B_GMOT0 = B_GALB0 + kGSets, B_CAND0 = B_GMOT0 + kGSets,
+       B_RES0 = B_CAND0 + kGSets, B_RES1, B_RAW, B_DISP, B_ACC0, B_ACC1, B_COUNT };
+static uint32_t bpp_of(int b) {
+    if (b < B_GALB0) return 16u;        // gpos, gnormal
+    if (b < B_GMOT0) return 4u;         // galbedo
+    if (b < B_CAND0) return 8u;         // gmotion
+    if (b < B_RES0) return 16u;         // candidate
+    if (b <= B_RES1) return 32u;
+    if (b == B_RAW) return 8u;
+    if (b == B_DISP) return 4u;
+    return 16u;                         // accumulation
+}
 struct GSlots { uint32_t g, gprev, aux; };   // physical sets: this frame's G-buffer, the previous logical slot's, and motion / candidate (= g under the pipeline)
-static const int kSpecDepth = 2;             // frames whose G-buffer + T-trace may run ahead
 
 // Device counters (unsigned long long each): [0..7] committed rays per stage {closest, any}; [8] halo overflow;
 // [9..12] PENDING rays of a G-buffer + T-trace pair that ran ahead of its frame (committed by its T-merge, dropped with a discarded speculation)
@@ -52,9 +64,8 @@ struct frt_renderer {
     bool own_stream = false;
     hipStream_t ahead = nullptr;           // FRT_FLAG_PIPELINE: G-buffer(f+1), T-trace(f+1)
     hipStream_t edge = nullptr;            // FRT_FLAG_PIPELINE, strips: the spatial pixel launches of the halo-dependent edge rows (beside the interior launch)
-    int spec_depth = 1;                    // frames speculated ahead. 2 was measured and buys nothing (2.204 vs 2.208 ms): the ahead stream is in order,
-                                           // frame f+2 cannot start before f+1's latency-bound tail has drained (FRT_SPEC_DEPTH: experiment knob, 0 .. kSpecDepth)
-    hipEvent_t ev_spix = nullptr, ev_tt[kSpecDepth] = {nullptr, nullptr}, ev_tail = nullptr, ev_tm = nullptr, ev_edge = nullptr;
+    int spec_depth = kSpecDepth;           // frames speculated ahead (FRT_SPEC_DEPTH: experiment knob, 0 .. kSpecDepth)
+    hipEvent_t ev_spix = nullptr, ev_tt[kSpecDepth] = {}, ev_tail = nullptr, ev_tm = nullptr, ev_edge = nullptr;
     bool tail_pending = false;             // work enqueued on `ahead` that the main stream has not been ordered behind yet
     bool edge_in_flight = false;
     uint32_t W = 0, H = 0, max_depth = 8, rb = 0, re = 0, flags = 0, motion_halo = 0;
@@ -108,7 +119,7 @@ static size_t arena_layout(uint32_t W, uint32_t H, size_t off[B_COUNT]) {
     size_t n = (size_t)W * H, cur = 0;
     for (int b = 0; b < B_COUNT; ++b) {
         if (off) off[b] = cur;
-        cur += (n * kBpp[b] + 255u) & ~(size_t)255u;
+        cur += (n * bpp_of(b) + 255u) & ~(size_t)255u;
     }
     return cur;
 }
@@ -409,7 +420,8 @@ void frt_renderer_destroy(frt_renderer* r) {
     if (r->stream || r->own_stream) (void)hipStreamSynchronize(r->stream);
     if (r->ahead) { (void)hipStreamSynchronize(r->ahead); (void)hipStreamDestroy(r->ahead); }
     if (r->edge) { (void)hipStreamSynchronize(r->edge); (void)hipStreamDestroy(r->edge); }
-    for (hipEvent_t e : {r->ev_spix, r->ev_tt[0], r->ev_tt[1], r->ev_tail, r->ev_tm, r->ev_edge}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {r->ev_spix, r->ev_tail, r->ev_tm, r->ev_edge}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->ev_tt) if (e) (void)hipEventDestroy(e);
     for (auto& t : r->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (hipEvent_t e : r->event_pool) (void)hipEventDestroy(e);
     for (void* p : r->scene_allocs) (void)hipFree(p);
@@ -463,7 +475,8 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         if (const char* e = getenv("FRT_AHEAD_PRIO")) prio = !strcmp(e, "low") ? lo : (!strcmp(e, "high") ? hi : prio);   // experiment knob
         HIP_TRY(hipStreamCreateWithPriority(&r->ahead, hipStreamNonBlocking, prio));
         HIP_TRY(hipStreamCreateWithPriority(&r->edge, hipStreamNonBlocking, prio));
-        for (hipEvent_t* e : {&r->ev_spix, &r->ev_tt[0], &r->ev_tt[1], &r->ev_tail, &r->ev_tm, &r->ev_edge}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&r->ev_spix, &r->ev_tail, &r->ev_tm, &r->ev_edge}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t& e : r->ev_tt) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (const char* e = getenv("FRT_SPEC_DEPTH")) r->spec_depth = std::max(0, std::min(kSpecDepth, atoi(e)));   // experiment knob
     }
     r->arena_bytes = arena_layout(r->W, r->H, r->off);
@@ -635,7 +648,9 @@ static GSlots alloc_g(frt_renderer* r, uint32_t frame_count) {
     const uint32_t L = frame_count & 1u;
     GSlots gs;
     if (!r->pipeline()) { gs.g = L; gs.gprev = L ^ 1u; gs.aux = 0u; r->logical_phys[0] = 0u; r->logical_phys[1] = 1u; return gs; }
-    gs.g = 3u - r->logical_phys[0] - r->logical_phys[1];
+    gs.g = r->logical_phys[L];      // two sets: the logical slot's own set (its frame's readers are done); more: a set neither slot points at
+    for (uint32_t p = 0; p < (uint32_t)kGSets; ++p)
+        if (p != r->logical_phys[0] && p != r->logical_phys[1]) { gs.g = p; break; }
     gs.gprev = r->logical_phys[L ^ 1u];
     gs.aux = gs.g;
     r->logical_phys[L] = gs.g;
@@ -909,7 +924,7 @@ int frt_renderer_buffer_info(const frt_renderer* r, int buf, int index, void** d
     int b = r ? buf_index(r, buf, index) : -1;
     if (b < 0) return fail(FRT_ERR_INVALID_ARG, "buffer_info: bad buffer");
     if (device_ptr) *device_ptr = r->buf(b);
-    if (bpp) *bpp = kBpp[b];
+    if (bpp) *bpp = bpp_of(b);
     return FRT_OK;
 }
 int frt_renderer_read_buffer(frt_renderer* r, int buf, int index, void* out) {
@@ -917,7 +932,7 @@ int frt_renderer_read_buffer(frt_renderer* r, int buf, int index, void* out) {
     if (b < 0 || !out) return fail(FRT_ERR_INVALID_ARG, "read_buffer: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
     { int rc_ = sync_all(r); if (rc_) return rc_; }
-    HIP_TRY(hipMemcpy(out, r->buf(b), (size_t)r->W * r->H * kBpp[b], hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, r->buf(b), (size_t)r->W * r->H * bpp_of(b), hipMemcpyDeviceToHost));
     return FRT_OK;
 }
 int frt_renderer_read_rows(frt_renderer* r, int buf, int index, uint32_t y0, uint32_t y1, void* out) {
@@ -925,7 +940,7 @@ int frt_renderer_read_rows(frt_renderer* r, int buf, int index, uint32_t y0, uin
     if (b < 0 || !out || y0 > y1 || y1 > r->H) return fail(FRT_ERR_INVALID_ARG, "read_rows: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
     { int rc_ = sync_all(r); if (rc_) return rc_; }
-    size_t pitch = (size_t)r->W * kBpp[b];
+    size_t pitch = (size_t)r->W * bpp_of(b);
     HIP_TRY(hipMemcpy(out, (uint8_t*)r->buf(b) + pitch * y0, pitch * (y1 - y0), hipMemcpyDeviceToHost));
     return FRT_OK;
 }
@@ -934,7 +949,7 @@ int frt_renderer_write_rows(frt_renderer* r, int buf, int index, uint32_t y0, ui
     if (b < 0 || !in || y0 > y1 || y1 > r->H) return fail(FRT_ERR_INVALID_ARG, "write_rows: bad arguments");
     HIP_TRY(hipSetDevice(r->device));
     { int rc_ = sync_all(r); if (rc_) return rc_; }
-    size_t pitch = (size_t)r->W * kBpp[b];
+    size_t pitch = (size_t)r->W * bpp_of(b);
     HIP_TRY(hipMemcpy((uint8_t*)r->buf(b) + pitch * y0, in, pitch * (y1 - y0), hipMemcpyHostToDevice));
     return FRT_OK;
 }
