@@ -28,9 +28,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 W, H, MAX_DEPTH = 1920, 1080, 8
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 STAGES = ("gbuffer", "temporal", "spatial", "post")
-# Compulsory per-pixel stream bytes of each kernel in this design: G-buffer write 44; temporal read 44+36+32,
-# write 32; spatial read 36+32, write 32+8; post read 68, write 20.
-B_PX = {"gbuffer": 44, "temporal": 144, "spatial": 108, "post": 88}
+# Compulsory per-pixel stream bytes of each kernel in this design: G-buffer write 44; temporal = T-trace (read 36, write the
+# 16-byte candidate) + T-merge (read candidate 16, G-buffer 36 + previous 36 + motion 8, previous spatial reservoir 32, write 32) = 212;
+# spatial read 36+32, write 32+8; post read 68, write 20.
+B_PX = {"gbuffer": 44, "temporal": 212, "spatial": 108, "post": 88}
 PMC_JSON = os.path.join(ROOT, "profiles", "r2_pmc.json")     # written by tools/pmc_to_json.py on the GPU box, committed
 
 
