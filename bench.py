@@ -134,7 +134,7 @@ def main():
     nl = scene.num_lights
     total = a.warmup + a.steps
     cam_ctl = frt.CameraController()
-    cams = [cam_ctl.build_uniform(W / H, f, nl) for f in range(max(total + 16, a.cpu_frames + 1))]
+    cams = [cam_ctl.build_uniform(W / H, f, nl) for f in range(max(total + 16 + a.steps, a.cpu_frames + 1))]
 
     # strips of equal WORK (probe render, identical on every rank), not equal height
     bounds = None
@@ -178,6 +178,24 @@ def main():
     s1 = r.stats()
 
     rays = (s1["rays_closest"] + s1["rays_any"]) - (s0["rays_closest"] + s0["rays_any"])
+    exposed_ms = None
+    if dist:
+        # What the halo transfers cost per frame: the same frame loop with the transfers switched off (the pixels of those frames are
+        # wrong — neighbours' rows are stale — but the work is the same), timed the same way; the difference is the exposed transfer time.
+        class _NoTransfers(StripPlan):
+            def transfers(self, frame, when="mid"):
+                return []
+        quiet = _NoTransfers(H, world, rank, bounds)
+        nq = max(8, a.steps // 2)
+        dist.barrier(); torch.cuda.synchronize()
+        tq = time.perf_counter()
+        for f in range(total, total + nq):
+            render_strip_frame(r, rows, quiet, cams[f], f, frt)
+        torch.cuda.synchronize(); dist.barrier()
+        quiet_ms = (time.perf_counter() - tq) / nq * 1e3
+        tqm = torch.tensor([quiet_ms], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(tqm, op=dist.ReduceOp.MAX)
+        exposed_ms = elapsed / a.steps * 1e3 - float(tqm.item())
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,14 +251,16 @@ def main():
         par = "1 GPU, two-stream schedule"
         if world > 1:
             par = (f"{world} work-balanced image strips {bounds}; per frame 2 halo exchanges per neighbour ({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'}): "
-                   "12 reservoir rows overlapped with the spatial stage's interior rows, 1 accumulation row on the post stream")
+                   "12 reservoir rows overlapped with the spatial stage's interior rows, 1 accumulation row posted a frame early; "
+                   f"exposed transfer time {exposed_ms:.3f} ms/frame (frame loop with vs without the transfers)")
         out = {
             "metric": "Mrays/sec, 1920x1080 8-bounce Cornell Box", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": frame_ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell Box 1920x1080, MAX_DEPTH 8, 1 candidate path/pixel/frame, 4-stage ReSTIR-PT frame (BASELINE.json configs[1])",
                        "rays_per_frame": rays / a.steps, "parallelism": par,
-                       "speculated_frames": s1["speculated_frames"] - s0["speculated_frames"], "queue_overflow": s1["queue_overflow"]},
+                       "speculated_frames": s1["speculated_frames"] - s0["speculated_frames"], "queue_overflow": s1["queue_overflow"],
+                       "exchange_exposed_ms": exposed_ms},
             "roofline": roof,
             "stage_ms": dict(zip(STAGES, ms)),
         }
