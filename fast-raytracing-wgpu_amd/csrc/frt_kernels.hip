@@ -431,21 +431,21 @@ __global__ void __launch_bounds__(kBlock, 4) bounce_kernel(SceneView sc, FrameVi
 // tests/hostcheck "stream"), so pixels and ray counts are unchanged.
 enum : uint32_t { M_IDLE = 0u, M_SHADOW = 1u, M_CLOSEST = 2u, M_SHADE = 3u };
 struct LaneRay { f3 o, d; float tmin, tmax; uint32_t cur; int sp; float t, u, v, det; uint32_t tri, inst; };
-static constexpr int kSliceNodes = 8;      // node steps per traversal round before the wave looks at its lanes again
+// (node steps per traversal round before the wave looks at its lanes again: the `slice` argument, 8 by default)
 
 __device__ __forceinline__ void lane_ray_begin(LaneRay& tr, f3 o, f3 d, float tmin, float tmax) {
     tr.o = o; tr.d = d; tr.tmin = tmin; tr.tmax = tmax; tr.cur = 0u; tr.sp = 0;
     tr.t = tmax; tr.u = 0.0f; tr.v = 0.0f; tr.det = 0.0f; tr.tri = 0xFFFFFFFFu; tr.inst = 0u;
 }
-// One traversal round for the lanes with `go` set: up to kSliceNodes node steps (while any of them is at an inner node), then one leaf
+// One traversal round for the lanes with `go` set: up to `slice` node steps (while any of them is at an inner node), then one leaf
 // (all its triangles) for the lanes that hold one. tr.cur == 0xFFFFFFFF afterwards: the ray is finished. Same box / triangle arithmetic and
 // the same visiting order per ray as trace() (frt_trace.hpp): the closest hit and the any-hit answer are the ones trace() finds.
-__device__ __forceinline__ void traverse_round(const SceneView& sc, LaneRay& tr, bool go, bool any_hit, uint32_t* stk, uint32_t stride) {
+__device__ __forceinline__ void traverse_round(const SceneView& sc, LaneRay& tr, bool go, bool any_hit, uint32_t* stk, uint32_t stride, int slice) {
     const uint32_t kDone = 0xFFFFFFFFu;
     f3 inv = mk3(prune_rcp(tr.d.x), prune_rcp(tr.d.y), prune_rcp(tr.d.z));
     f3 oinv = mk3(-tr.o.x * inv.x, -tr.o.y * inv.y, -tr.o.z * inv.z);
 #pragma nounroll
-    for (int it = 0; it < kSliceNodes; ++it) {
+    for (int it = 0; it < slice; ++it) {
         const bool at_node = go && !(tr.cur & 0x80000000u);
         if (__ballot(at_node) == 0ull) break;
         if (at_node) {
@@ -488,7 +488,7 @@ __device__ __forceinline__ void traverse_round(const SceneView& sc, LaneRay& tr,
 }
 
 template <int STAGE>
-__global__ void __launch_bounds__(kBlock, 4) stream_kernel(SceneView sc, FrameView fv, ContQueue qin, uint32_t* head, uint32_t d0, uint32_t refill_min, uint32_t shade_min) {
+__global__ void __launch_bounds__(kBlock, 4) stream_kernel(SceneView sc, FrameView fv, ContQueue qin, uint32_t* head, uint32_t d0, uint32_t refill_min, uint32_t shade_min, int slice) {
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     __shared__ uint32_t s_cnt[2];
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(kBlock, 4) stream_kernel(SceneView sc, FrameVi
         } else {
             // ---- traversal round
             const bool go = mode == M_SHADOW || mode == M_CLOSEST;
-            traverse_round(sc, tr, go, mode == M_SHADOW, c.stk, c.stride);
+            traverse_round(sc, tr, go, mode == M_SHADOW, c.stk, c.stride, slice);
             if (go && tr.cur == 0xFFFFFFFFu) {
                 if (mode == M_SHADOW) {
                     s.accumulated = s.accumulated + (tr.tri == 0xFFFFFFFFu ? contrib : dark);
@@ -888,8 +888,8 @@ hipError_t launch_trace_continuations(int stage, const SceneView& sc, const Fram
     if (stage != 1 && stage != 2) return hipErrorInvalidValue;
     if (L.stream && L.ncuts == 1 && L.cuts[0] < fv.max_depth) {
         const uint32_t wgs = std::max(1u, std::min(L.num_cus * 4u, (L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock));
-        if (stage == 1) hipLaunchKernelGGL(stream_kernel<1>, dim3(wgs), dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), L.counts + 1, L.cuts[0], L.refill_min, L.shade_min);
-        else hipLaunchKernelGGL(stream_kernel<2>, dim3(wgs), dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), L.counts + 1, L.cuts[0], L.refill_min, L.shade_min);
+        if (stage == 1) hipLaunchKernelGGL(stream_kernel<1>, dim3(wgs), dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), L.counts + 1, L.cuts[0], L.refill_min, L.shade_min, (int)L.slice);
+        else hipLaunchKernelGGL(stream_kernel<2>, dim3(wgs), dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), L.counts + 1, L.cuts[0], L.refill_min, L.shade_min, (int)L.slice);
         return hipGetLastError();
     }
     if (L.refill && L.ncuts == 1 && L.cuts[0] < fv.max_depth) {

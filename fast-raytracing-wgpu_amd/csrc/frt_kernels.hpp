@@ -12,7 +12,7 @@ static constexpr int kMaxCuts = 4;
 struct TraceLaunch { uint32_t ncuts; uint32_t cuts[kMaxCuts]; uint32_t* qwords[2]; uint32_t* counts; uint32_t capacity; uint32_t* overflow;
                      uint32_t* zero_counts; uint32_t* tile_state;
                      // resident form (frt_kernels.hip: resident_*_kernel): BVH cached in LDS, persistent workgroups
-                     bool stream; uint32_t shade_min;   // single cut: stream_kernel (resumable traversal + lane refill); shade when >= shade_min lanes wait
+                     bool stream; uint32_t shade_min, slice;   // single cut: stream_kernel (resumable traversal + lane refill); shade when >= shade_min lanes wait
                      bool refill; uint32_t refill_min;   // single cut: bounce_kernel (lane refill) instead of the continuation launches; refill when >= refill_min lanes are free
                      bool resident; uint32_t res_nodes; bool res_tris; uint32_t num_cus; uint32_t res_batch;   // res_batch: 0 = chosen from the tile count
                      uint32_t* work; };   // 2 x (1 + kMaxCuts) words: {next, ticket} of the pixel launch, then of each continuation launch; zero between launches

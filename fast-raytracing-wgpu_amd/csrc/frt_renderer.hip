@@ -86,7 +86,7 @@ struct frt_renderer {
     uint32_t qparity[2] = {0, 0};
     uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box
     uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state, or null
-    bool stream_mode = false; uint32_t shade_min = 32;   // stream kernel (resumable traversal) instead of continuation launches
+    bool stream_mode = false; uint32_t shade_min = 32, stream_slice = 8;   // stream kernel (resumable traversal) instead of continuation launches
     bool refill = false; uint32_t refill_min = 16;   // bounce kernel with lane refill (single cut) instead of continuation launches
     bool resident = false;                 // traced stages through the resident kernels (BVH cached in LDS, persistent workgroups)
     uint32_t res_nodes = 0; bool res_tris = false; uint32_t num_cus = 0, res_batch = 0;
@@ -537,6 +537,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         r->resident = false;
         if (const char* e = getenv("FRT_RESIDENT")) r->resident = atoi(e) != 0 && r->res_nodes > 0 && !(r->flags & FRT_FLAG_COMPACTION);
         if (const char* e = getenv("FRT_STREAM")) { r->stream_mode = atoi(e) != 0; if (atoi(e) > 1) r->shade_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: n > 1 = shade_min
+        if (const char* e = getenv("FRT_STREAM_SLICE")) r->stream_slice = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("FRT_REFILL")) { r->refill = atoi(e) != 0; if (atoi(e) > 1) r->refill_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: 0 off, 1 on, n > 1: refill when >= n lanes are free
         if (const char* e = getenv("FRT_RES_BATCH")) r->res_batch = (uint32_t)atoi(e);      // experiment knob: tiles per fetch (1, 2, 4)
         if (const char* e = getenv("FRT_RES_TRIS")) { if (atoi(e) == 0) r->res_tris = false; }   // experiment knob: triangles from L2
@@ -586,7 +587,7 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
 // run beside the interior one); the continuation launches use the pairs behind them.
 static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, TraceLaunch& L, int work_slot = 0) {
     memset(&L, 0, sizeof(L));
-    L.refill = r->refill; L.refill_min = r->refill_min; L.stream = r->stream_mode; L.shade_min = r->shade_min;
+    L.refill = r->refill; L.refill_min = r->refill_min; L.stream = r->stream_mode; L.shade_min = r->shade_min; L.slice = r->stream_slice;
     L.resident = r->resident; L.res_nodes = r->res_nodes; L.res_tris = r->res_tris; L.num_cus = r->num_cus; L.res_batch = r->res_batch;
     L.work = r->d_work + ((size_t)(stage - 1) * kWorkSlots + (size_t)work_slot) * 2;
     const bool cut = stage_is_cut(r) && r->qcap > 0;

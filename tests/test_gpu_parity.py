@@ -317,7 +317,10 @@ def test_config2_4k_eight_strips_equal_whole(gpu):
     cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(N)]
     whole = frt.Renderer(fs, W, H, flags=frt.FLAG_OVERLAP_POST)
     for c in cams: whole.render(c)
-    want = whole.read_accum(); total = whole.stats()["rays_closest"] + whole.stats()["rays_any"]
+    want = whole.read_accum(); st = whole.stats(); total = st["rays_closest"] + st["rays_any"]
+    # footprint at 4K: per-pixel arena + continuation queues (one 22-word and one 30-word buffer of `capacity` slots)
+    footprint = frt.Renderer.arena_bytes(W, H) + st["queue_capacity"] * (22 + 30) * 4
+    assert st["queue_overflow"] == 0 and footprint < 2.5e9, (footprint, st)
     del whole
     plans = [StripPlan(H, 8, k) for k in range(8)]
     assert all(p.row_end - p.row_begin == 270 for p in plans)
