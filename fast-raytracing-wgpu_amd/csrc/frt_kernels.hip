@@ -272,6 +272,25 @@ __device__ __forceinline__ void finish_path(PathCtx& c, uint32_t pix, const Rese
     else spatial_tail(c, pix, r, s.accumulated, s.v1_pos);
 }
 
+// Slots for the lanes of a workgroup that want one, with ONE atomic for the whole workgroup. Every thread of the workgroup must call it
+// (three barriers inside). s_tmp: 8 words of LDS.
+__device__ __forceinline__ uint32_t workgroup_reserve(uint32_t* counter, bool want, uint32_t* s_tmp) {
+    const unsigned long long m = __ballot(want);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) s_tmp[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const uint32_t total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+        s_tmp[4] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_tmp[4];
+    for (uint32_t w = 0; w < wave; ++w) base += s_tmp[w];
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    __syncthreads();
+    return base + rank;
+}
+
 // Runs bounces [d0, d1) of the lane's path and parks a survivor in `q`; when the queue is full the lane goes on to MAX_DEPTH itself.
 // On return the path is either parked (true: state stored) or finished (false: s holds the final radiance).
 template <int VARIANT, class Ctx>
@@ -282,10 +301,12 @@ __device__ __forceinline__ bool run_segment_and_park(Ctx& c, LoopState& s, uint3
     for (int trip = 0; trip < 2; ++trip) {
         if (run) path_loop<VARIANT>(c, s, d0, d1);
         if (trip == 1) break;
-        const uint32_t slot = wave_reserve(q.count, s.alive);
-        parked = s.alive && slot < q.capacity;
+        uint32_t region = 0u, rcap = q.capacity;
+        if (q.nsub > 1u) { region = (blockIdx.x + blockIdx.y * gridDim.x) % q.nsub; rcap = q.capacity / q.nsub; }
+        const uint32_t slot = wave_reserve(q.count + region, s.alive);
+        parked = s.alive && slot < rcap;
         run = s.alive && !parked;
-        if (parked) cont_store(q, slot, pix, c.rng, owned, s, r);
+        if (parked) cont_store(q, region * rcap + slot, pix, c.rng, owned, s, r);
         if (__ballot(run) == 0ull) break;      // wave-uniform
         note_queue_overflow(q, run);
         d0 = d1; d1 = c.fv.max_depth;          // no further cut for a path that could not be parked
@@ -294,10 +315,11 @@ __device__ __forceinline__ bool run_segment_and_park(Ctx& c, LoopState& s, uint3
 }
 
 template <int STAGE>
-__global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, TileOrder to, uint32_t* zero_counts) {
+__global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, TileOrder to, uint32_t* zero_counts, bool wg_park) {
     constexpr int THREADS = kBlock;
     __shared__ uint32_t s_stack[kStackDepth * THREADS];
     __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_tmp[8];
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
@@ -321,7 +343,25 @@ __global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameVie
         } else if (spatial_neighbors(c, pix, r)) { seed = r.y; traced = true; }
         if (traced) path_head<VARIANT>(c, pix, seed, s);
     }
-    const bool parked = run_segment_and_park<VARIANT>(c, s, 1u, cut < fv.max_depth ? cut : fv.max_depth, q, pix, counted, STAGE == 2 ? &r : nullptr);
+    // bounces [1, cut), then park the survivors: ONE atomic for the workgroup's four waves (tens of thousands of atomics per launch on one
+    // address are served at ~13 ns each: 32,640 wave-level reservations = 0.42 ms of a 0.8 ms kernel's life); a lane that finds the queue
+    // full keeps its path and finishes it in place
+    uint32_t d0 = 1u, d1 = cut < fv.max_depth ? cut : fv.max_depth;
+    bool run = s.alive, parked = false;
+#pragma nounroll
+    for (int trip = 0; trip < 2; ++trip) {      // (a loop so that path_loop is instantiated once)
+        if (run) path_loop<VARIANT>(c, s, d0, d1);
+        if (trip == 1) break;
+        uint32_t region = 0u, rcap = q.capacity;
+        if (q.nsub > 1u) { region = (blockIdx.x + blockIdx.y * gridDim.x) % q.nsub; rcap = q.capacity / q.nsub; }
+        const uint32_t slot = wg_park ? workgroup_reserve(q.count + region, s.alive, s_tmp) : wave_reserve(q.count + region, s.alive);
+        parked = s.alive && slot < rcap;
+        run = s.alive && !parked;
+        if (parked) cont_store(q, region * rcap + slot, pix, c.rng, counted, s, STAGE == 2 ? &r : nullptr);
+        if (__ballot(run) == 0ull) break;      // wave-uniform; no barrier follows
+        note_queue_overflow(q, run);
+        d0 = d1; d1 = fv.max_depth;
+    }
     if (traced && !parked) finish_path<STAGE>(c, pix, r, s);
     flush_ray_counters(fv, counted ? c.n_closest : 0u, counted ? c.n_any : 0u, s_cnt);   // (contains a barrier: every wave is done)
     // this tile's share of its row's cost for the next launch's sweep direction: the time the workgroup took (ray counts mislead:
@@ -576,6 +616,203 @@ __global__ void __launch_bounds__(kBlock, 4) stream_kernel(SceneView sc, FrameVi
     flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
 }
 
+// ---- ray-level wavefront (opt-in, FRT_WAVEFRONT=1) -----------------------------------------------------------------------------------
+// What the experiments above point to: the traced kernels lose their lanes to wave-level TRAVERSAL divergence, so traversal
+// gets a kernel of its own. After the pixel kernel (primary hit only, cut at depth 1) each bounce depth d is two launches:
+//   wf_trace_kernel   persistent waves take RAYS — the closest-hit ray of a parked path's iteration d, or the shadow ray its iteration d-1
+//                     left pending — from an item list, one ray per lane, and a lane that finishes its ray takes the next one (resumable
+//                     traverse_round, refill by ballot + one atomic per wave): no lane waits for the slowest ray of its wave, and with
+//                     ~50 VGPRs the kernel runs 8 waves per SIMD, twice the latency hiding of the shading kernels;
+//   wf_shade_kernel   one lane per parked path, dense: adds the pending estimate (lit or dark), shades the hit with bounce_shade — the
+//                     iteration with its rays pulled apart, frt_mono.hpp, checked against path_loop on the CPU — and parks the survivor
+//                     (and any path that still owes a shadow ray) for depth d + 1, emitting its ray items.
+// Records are the continuation records (30 words) + the pending shadow ray and its two possible contributions (14 words); hits come back
+// through a 7-word side buffer. Same per-path arithmetic and rand() order as path_loop: pixels and ray counts unchanged.
+static constexpr int kWfWords = 44, kWfSub = 8;
+enum : uint32_t { WF_SHADOW = 8u, WF_ENDED = 16u };
+// Queues and item lists are cut into kWfSub regions with a counter each (frt_mono.hpp: ContQueue::nsub): a workgroup parks into the region
+// blockIdx % kWfSub, one atomic per WORKGROUP and counter; the trace kernel takes its rays by static chunking, no atomics at all.
+// (First build: one counter per list, one atomic per wave: every launch cost >= 120 us and the stages were 4x slower than the plain kernels.)
+struct WfPass {
+    uint32_t* qin; const uint32_t* n_in;          // records of depth d (kWfWords x capacity, SoA), counts per region
+    uint32_t* qout; uint32_t* n_out;              // records of depth d + 1
+    const uint32_t* items_in; const uint32_t* n_items_in;   // rays to trace for depth d: slot << 1 | kind (0 closest, 1 shadow), 2 x capacity, regions; null = every record, closest
+    uint32_t* items_out; uint32_t* n_items_out;
+    uint32_t* hits;                               // 7 x capacity: t, u, v, tri, inst, front | unoccluded
+    uint32_t capacity;
+    uint32_t* overflow;
+};
+
+template <int STACK>
+__global__ void __launch_bounds__(kBlock, 8) wf_trace_kernel(SceneView sc, FrameView fv, WfPass io, uint32_t refill_min, int slice) {
+    __shared__ uint32_t s_stack[STACK * kBlock];
+    __shared__ uint32_t s_cnt[2];
+    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const size_t cap = io.capacity;
+    const uint32_t rcap = io.capacity / (uint32_t)kWfSub, icap = 2u * rcap;
+    // chunks of 64 items, region after region; wave w takes chunks w, w + W, w + 2W, ...
+    uint32_t cnt[kWfSub], first_chunk[kWfSub + 1];
+    first_chunk[0] = 0u;
+#pragma unroll
+    for (int j = 0; j < kWfSub; ++j) {
+        const uint32_t v = io.items_in ? io.n_items_in[j] : io.n_in[j], lim = io.items_in ? icap : rcap;
+        cnt[j] = v < lim ? v : lim;
+        first_chunk[j + 1] = first_chunk[j] + (cnt[j] + 63u) / 64u;
+    }
+    const uint32_t total_chunks = first_chunk[kWfSub], n_waves = gridDim.x * (uint32_t)(kBlock / 64);
+    uint32_t chunk = blockIdx.x * (uint32_t)(kBlock / 64) + (threadIdx.x >> 6);
+    uint32_t cur = 0u, end = 0u, region = 0u;      // wave-uniform: next item of the current chunk, its end, its region
+    bool more = chunk < total_chunks;
+    auto open_chunk = [&]() {
+        region = 0u;
+#pragma unroll
+        for (int j = 1; j < kWfSub; ++j) if (chunk >= first_chunk[j]) region = (uint32_t)j;
+        uint32_t c0 = 0u, n = 0u;
+#pragma unroll
+        for (int j = 0; j < kWfSub; ++j) if (region == (uint32_t)j) { c0 = first_chunk[j]; n = cnt[j]; }
+        cur = (chunk - c0) * 64u;
+        end = cur + 64u < n ? cur + 64u : n;
+    };
+    if (more) open_chunk();
+    uint32_t* stk = &s_stack[threadIdx.x];
+    LaneRay tr;
+    lane_ray_begin(tr, splat3(0.0f), splat3(0.0f), 0.0f, 0.0f);
+    uint32_t item = 0u, cnt_closest = 0u, cnt_any = 0u;
+    bool busy = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        const uint32_t k = (uint32_t)__popcll(idle);
+        if (more && k >= refill_min) {
+            const uint32_t avail = end - cur, take = k < avail ? k : avail;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (!busy && rank < take) {
+                const uint32_t idx = cur + rank;
+                item = io.items_in ? io.items_in[(size_t)region * icap + idx] : ((region * rcap + idx) << 1);
+                const uint32_t slot = item >> 1;
+                const uint32_t* w = io.qin + slot;
+                const bool owned = (w[2 * cap] & 4u) != 0u;
+                if (item & 1u) {
+                    lane_ray_begin(tr, mk3(u2f(w[30 * cap]), u2f(w[31 * cap]), u2f(w[32 * cap])), mk3(u2f(w[33 * cap]), u2f(w[34 * cap]), u2f(w[35 * cap])),
+                                   u2f(w[36 * cap]), u2f(w[37 * cap]));
+                    if (owned) cnt_any++;
+                } else {
+                    LoopState s;
+                    s.pos = mk3(u2f(w[3 * cap]), u2f(w[4 * cap]), u2f(w[5 * cap]));
+                    s.ffnormal = mk3(u2f(w[6 * cap]), u2f(w[7 * cap]), u2f(w[8 * cap]));
+                    s.next_dir = mk3(u2f(w[15 * cap]), u2f(w[16 * cap]), u2f(w[17 * cap]));
+                    lane_ray_begin(tr, bounce_origin(s), s.next_dir, 0.001f, 100.0f);
+                    if (owned) cnt_closest++;
+                }
+                busy = true;
+            }
+            cur += take;
+            if (cur == end) {
+                chunk += n_waves;
+                more = chunk < total_chunks;
+                if (more) open_chunk();
+            }
+        }
+        if (__ballot(busy) == 0ull) {
+            if (!more) break;
+            continue;
+        }
+        traverse_round(sc, tr, busy, (item & 1u) != 0u, stk, (uint32_t)kBlock, slice);
+        if (busy && tr.cur == 0xFFFFFFFFu) {
+            uint32_t* h = io.hits + (item >> 1);
+            if (item & 1u) h[6 * cap] = tr.tri == 0xFFFFFFFFu ? 1u : 0u;
+            else {
+                bool front = false;
+                if (tr.tri != 0xFFFFFFFFu) { front = tr.det > 0.0f; if (sc.instances[tr.inst].flip) front = !front; }
+                h[0] = f2u(tr.t); h[1 * cap] = f2u(tr.u); h[2 * cap] = f2u(tr.v); h[3 * cap] = tr.tri; h[4 * cap] = tr.inst; h[5 * cap] = front ? 1u : 0u;
+            }
+            busy = false;
+        }
+    }
+    flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(kBlock, 4) wf_shade_kernel(SceneView sc, FrameView fv, WfPass io, uint32_t depth) {
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_tmp[8];
+    const uint32_t region = blockIdx.x % (uint32_t)kWfSub, blk = blockIdx.x / (uint32_t)kWfSub, nblk = gridDim.x / (uint32_t)kWfSub;
+    const uint32_t rcap = io.capacity / (uint32_t)kWfSub, icap = 2u * rcap, rbase = region * rcap;
+    const uint32_t n = io.n_in[region] < rcap ? io.n_in[region] : rcap;
+    if (blk * (uint32_t)kBlock >= n) return;   // uniform per workgroup
+    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    constexpr int VARIANT = STAGE == 1 ? 0 : 1;
+    const size_t cap = io.capacity;
+    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
+    uint32_t cnt_closest = 0u, cnt_any = 0u;
+    for (uint32_t base = blk * (uint32_t)kBlock; base < n; base += nblk * (uint32_t)kBlock) {
+        const uint32_t local = base + threadIdx.x, slot = rbase + local;
+        const bool have = local < n;
+        LoopState s;
+        s.alive = false;
+        ReservoirView r = zero_reservoir();
+        uint32_t pix = 0u, flags = 0u;
+        bool owned = false, keep = false, want = false, ended = true;
+        ShadowReq req;
+        req.want = false; req.add_now = false; req.contrib = req.dark = req.o = req.d = splat3(0.0f); req.tmin = req.tmax = 0.0f;
+        c.n_closest = 0u; c.n_any = 0u;
+        if (have) {
+            ContQueue qv; qv.words = io.qin; qv.count = nullptr; qv.capacity = io.capacity; qv.overflow = nullptr; qv.nsub = 1u;
+            cont_load(qv, slot, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+            const uint32_t* w = io.qin + slot;
+            flags = w[2 * cap];
+            const uint32_t* h = io.hits + slot;
+            if (flags & WF_SHADOW) {      // the estimate the previous iteration left pending
+                const bool lit = h[6 * cap] != 0u;
+                const int o = lit ? 38 : 41;
+                s.accumulated = s.accumulated + mk3(u2f(w[(size_t)o * cap]), u2f(w[(size_t)(o + 1) * cap]), u2f(w[(size_t)(o + 2) * cap]));
+            }
+            ended = (flags & WF_ENDED) != 0u;
+            if (!ended) {
+                HitRec hr;
+                hr.t = u2f(h[0]); hr.u = u2f(h[1 * cap]); hr.v = u2f(h[2 * cap]); hr.tri = h[3 * cap]; hr.inst = h[4 * cap]; hr.front = h[5 * cap] != 0u;
+                bounce_shade<VARIANT>(c, s, depth, hr, req);
+                if (!req.want) s.accumulated = s.accumulated + (req.add_now ? req.contrib : req.dark);
+                ended = !s.alive;
+                want = req.want;
+            }
+            keep = want || !ended;
+        }
+        const uint32_t lo = workgroup_reserve(io.n_out + region, keep, s_tmp);
+        const bool fits = keep && lo < rcap;
+        const bool overflowed = keep && !fits;
+        if (overflowed) {      // the next queue is full: finish the path in place (never dropped)
+            if (want) s.accumulated = s.accumulated + (c.any(req.o, req.d, req.tmin, req.tmax) ? req.dark : req.contrib);
+            if (!ended) { s.alive = true; path_loop<VARIANT>(c, s, depth + 1u, fv.max_depth); }
+        }
+        note_queue_overflow(ContQueue{nullptr, nullptr, 0u, io.overflow, 1u}, overflowed);
+        const uint32_t slot_out = rbase + lo;
+        if (fits) {
+            ContQueue qo; qo.words = io.qout; qo.count = nullptr; qo.capacity = io.capacity; qo.overflow = nullptr; qo.nsub = 1u;
+            s.alive = true;
+            cont_store(qo, slot_out, pix, c.rng, owned, s, STAGE == 2 ? &r : nullptr);
+            uint32_t* w = io.qout + slot_out;
+            w[2 * cap] = (s.previous_was_diffuse ? 1u : 0u) | (s.is_glass ? 2u : 0u) | (owned ? 4u : 0u) | (want ? WF_SHADOW : 0u) | (ended ? WF_ENDED : 0u);
+            if (want) {
+                const float f[14] = {req.o.x, req.o.y, req.o.z, req.d.x, req.d.y, req.d.z, req.tmin, req.tmax,
+                                     req.contrib.x, req.contrib.y, req.contrib.z, req.dark.x, req.dark.y, req.dark.z};
+#pragma unroll
+                for (int k = 0; k < 14; ++k) w[(size_t)(30 + k) * cap] = f2u(f[k]);
+            }
+        }
+        // ray items of depth + 1: the next closest-hit ray, the pending shadow ray (two reservations, one atomic each per workgroup)
+        const uint32_t ic = workgroup_reserve(io.n_items_out + region, fits && !ended, s_tmp);
+        if (fits && !ended && ic < icap) io.items_out[(size_t)region * icap + ic] = slot_out << 1;
+        const uint32_t is = workgroup_reserve(io.n_items_out + region, fits && want, s_tmp);
+        if (fits && want && is < icap) io.items_out[(size_t)region * icap + is] = (slot_out << 1) | 1u;
+        if (have && !fits) finish_path<STAGE>(c, pix, r, s);      // ended with nothing pending, or finished in place
+        if (owned) { cnt_closest += c.n_closest; cnt_any += c.n_any; }
+    }
+    flush_ray_counters(fv, cnt_closest, cnt_any, s_cnt);
+}
+
 // ---- resident kernels: the BVH lives in LDS ---------------------------------------------------------------------------------------
 // Same stages, same arithmetic, another execution shape. One persistent 1024-thread workgroup per CU (16 waves = the 4 waves per SIMD the
 // register budget allows anyway) first copies the quantized pair nodes — all of them when they fit, the top of the breadth-first tree
@@ -820,7 +1057,7 @@ __global__ void __launch_bounds__(kBlock) post_jitter_kernel(FrameView fv) {
 static dim3 grid_for(const FrameView& fv) { return dim3((fv.W + 15u) / 16u, (fv.y1 - fv.y0 + 15u) / 16u, 1u); }
 static bool empty_rows(const FrameView& fv) { return fv.y1 <= fv.y0 || fv.W == 0u; }
 static ContQueue queue_of(const TraceLaunch& L, uint32_t k) {
-    ContQueue q; q.words = L.qwords[k & 1u]; q.count = L.counts + k; q.capacity = L.capacity; q.overflow = L.overflow; return q;
+    ContQueue q; q.words = L.qwords[k & 1u]; q.count = L.counts + k; q.capacity = L.capacity; q.overflow = L.overflow; q.nsub = L.wavefront ? (uint32_t)kWfSub : 1u; return q;
 }
 static uint32_t first_cut(const TraceLaunch& L, const FrameView& fv) { return L.ncuts ? L.cuts[0] : fv.max_depth; }
 
@@ -877,8 +1114,8 @@ hipError_t launch_trace_pixels(int stage, const SceneView& sc, const FrameView& 
         return hipGetLastError();
     }
     TileOrder to{L.tile_state, grid.y};
-    if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), to, L.zero_counts);
-    else hipLaunchKernelGGL(pixel_kernel<2>, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), to, L.zero_counts);
+    if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), to, L.zero_counts, L.wg_park);
+    else hipLaunchKernelGGL(pixel_kernel<2>, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), to, L.zero_counts, L.wg_park);
     return hipGetLastError();
 }
 bool trace_has_continuations(const TraceLaunch& L, uint32_t max_depth) { return L.ncuts > 0 && L.cuts[0] < max_depth; }
@@ -886,6 +1123,25 @@ bool trace_has_continuations(const TraceLaunch& L, uint32_t max_depth) { return 
 // workgroups beyond the queue's length leave at once). Resident form: persistent workgroups take 64-path chunks from a counter.
 hipError_t launch_trace_continuations(int stage, const SceneView& sc, const FrameView& fv, hipStream_t stream, const TraceLaunch& L) {
     if (stage != 1 && stage != 2) return hipErrorInvalidValue;
+    if (L.wavefront && L.ncuts == 1 && L.cuts[0] < fv.max_depth) {
+        // counter block (zeroed by the caller before the pixel launch): records of pass k per region at [8 k .. 8 k + 8), items at 512 + 8 k
+        const uint32_t rblocks = std::max(1u, (L.capacity / (uint32_t)kWfSub + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
+        const uint32_t sgrid = rblocks * (uint32_t)kWfSub;
+        const uint32_t tgrid = std::max(1u, std::min(L.num_cus * 8u, (2u * L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock));
+        for (uint32_t d = L.cuts[0]; d <= fv.max_depth; ++d) {
+            const uint32_t k = d - L.cuts[0];
+            WfPass io;
+            io.qin = L.wf_words[k & 1u]; io.n_in = L.counts + 8u * k; io.qout = L.wf_words[(k + 1u) & 1u]; io.n_out = L.counts + 8u * (k + 1u);
+            io.items_in = k == 0u ? nullptr : L.wf_items[k & 1u]; io.n_items_in = L.counts + 512 + 8u * k;
+            io.items_out = L.wf_items[(k + 1u) & 1u]; io.n_items_out = L.counts + 512 + 8u * (k + 1u);
+            io.hits = L.wf_hits; io.capacity = L.capacity; io.overflow = L.overflow;
+            if (sc.bvh_depth <= 17u) hipLaunchKernelGGL(wf_trace_kernel<16>, dim3(tgrid), dim3(kBlock), 0, stream, sc, fv, io, L.refill_min, (int)L.slice);
+            else hipLaunchKernelGGL(wf_trace_kernel<32>, dim3(tgrid), dim3(kBlock), 0, stream, sc, fv, io, L.refill_min, (int)L.slice);
+            if (stage == 1) hipLaunchKernelGGL(wf_shade_kernel<1>, dim3(sgrid), dim3(kBlock), 0, stream, sc, fv, io, d);
+            else hipLaunchKernelGGL(wf_shade_kernel<2>, dim3(sgrid), dim3(kBlock), 0, stream, sc, fv, io, d);
+        }
+        return hipGetLastError();
+    }
     if (L.stream && L.ncuts == 1 && L.cuts[0] < fv.max_depth) {
         const uint32_t wgs = std::max(1u, std::min(L.num_cus * 4u, (L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock));
         if (stage == 1) hipLaunchKernelGGL(stream_kernel<1>, dim3(wgs), dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), L.counts + 1, L.cuts[0], L.refill_min, L.shade_min, (int)L.slice);

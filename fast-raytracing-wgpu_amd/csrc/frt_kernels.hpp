@@ -12,6 +12,8 @@ static constexpr int kMaxCuts = 4;
 struct TraceLaunch { uint32_t ncuts; uint32_t cuts[kMaxCuts]; uint32_t* qwords[2]; uint32_t* counts; uint32_t capacity; uint32_t* overflow;
                      uint32_t* zero_counts; uint32_t* tile_state;
                      // resident form (frt_kernels.hip: resident_*_kernel): BVH cached in LDS, persistent workgroups
+                     bool wg_park;   // pixel kernel: one queue reservation per workgroup instead of one per wave
+                     bool wavefront; uint32_t* wf_words[2]; uint32_t* wf_items[2]; uint32_t* wf_hits;   // ray-level wavefront (frt_kernels.hip: wf_*_kernel); counts = its 96-word counter block
                      bool stream; uint32_t shade_min, slice;   // single cut: stream_kernel (resumable traversal + lane refill); shade when >= shade_min lanes wait
                      bool refill; uint32_t refill_min;   // single cut: bounce_kernel (lane refill) instead of the continuation launches; refill when >= refill_min lanes are free
                      bool resident; uint32_t res_nodes; bool res_tris; uint32_t num_cus; uint32_t res_batch;   // res_batch: 0 = chosen from the tile count

@@ -379,7 +379,9 @@ FRT_HD void path_loop_split(Ctx& c, LoopState& s, uint32_t depth_begin, uint32_t
 // 256-byte rows per word. 22 words (88 B) per path; the spatial stage adds its merged reservoir (8 words).
 // `count` may run past `capacity`: a path that finds the queue full is finished in place by the lane that holds it (never dropped) and
 // counted in `overflow`; readers use min(*count, capacity) slots.
-struct ContQueue { uint32_t* words; uint32_t* count; uint32_t capacity; uint32_t* overflow; };
+// nsub > 1: the queue is cut into nsub regions of capacity / nsub slots, each with its own counter (count[0 .. nsub)): tens of thousands of
+// atomics on ONE address cost ~13 ns each on this chip (measured: 8,192 waves taking one ticket each = 120 us), eight addresses run side by side.
+struct ContQueue { uint32_t* words; uint32_t* count; uint32_t capacity; uint32_t* overflow; uint32_t nsub; };
 static constexpr int kContWordsPath = 22, kContWordsSpatial = 30;
 
 FRT_HD void cont_store(const ContQueue& q, uint32_t slot, uint32_t pix, uint32_t rng, bool owned, const LoopState& s, const ReservoirView* r) {

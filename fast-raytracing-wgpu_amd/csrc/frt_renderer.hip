@@ -86,6 +86,10 @@ struct frt_renderer {
     uint32_t qparity[2] = {0, 0};
     uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box
     uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state, or null
+    bool wg_park = true;                   // pixel kernels reserve queue slots once per workgroup (FRT_WG_PARK=0: once per wave, experiment knob)
+    bool wavefront = false;                // ray-level wavefront (FRT_WAVEFRONT=1): per bounce depth a trace launch and a shade launch
+    uint32_t* d_wf_words[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint32_t* d_wf_items[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint32_t* d_wf_hits[2] = {nullptr, nullptr}; uint32_t* d_wf_counts = nullptr;   // per stage: records x 2, item lists x 2, hit buffer; 2 x 96 counters
     bool stream_mode = false; uint32_t shade_min = 32, stream_slice = 8;   // stream kernel (resumable traversal) instead of continuation launches
     bool refill = false; uint32_t refill_min = 16;   // bounce kernel with lane refill (single cut) instead of continuation launches
     bool resident = false;                 // traced stages through the resident kernels (BVH cached in LDS, persistent workgroups)
@@ -413,6 +417,9 @@ uint64_t frt_renderer_arena_bytes(uint32_t width, uint32_t height) { return aren
 
 static void free_queues(frt_renderer* r) {
     for (auto& st : r->d_qwords) for (uint32_t*& p : st) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto& st : r->d_wf_words) for (uint32_t*& p : st) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto& st : r->d_wf_items) for (uint32_t*& p : st) { if (p) (void)hipFree(p); p = nullptr; }
+    for (uint32_t*& p : r->d_wf_hits) { if (p) (void)hipFree(p); p = nullptr; }
 }
 void frt_renderer_destroy(frt_renderer* r) {
     if (!r) return;
@@ -429,12 +436,14 @@ void frt_renderer_destroy(frt_renderer* r) {
     if (r->d_counters) (void)hipFree(r->d_counters);
     free_queues(r);
     if (r->d_qcount) (void)hipFree(r->d_qcount);
+    if (r->d_wf_counts) (void)hipFree(r->d_wf_counts);
     if (r->d_tiles) (void)hipFree(r->d_tiles);
     if (r->d_work) (void)hipFree(r->d_work);
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
 
+static const size_t kWfCounterWords = 1024;                        // per stage: record counts per pass and region, item counts at +512
 static const int kWorkSlots = 3 + kMaxCuts;                       // pixel launch (interior / whole), the two edge launches, one per continuation launch
 static const size_t kWorkWords = 2 * kWorkSlots * 2;               // [stage][slot]{next, ticket}
 static const size_t kQcountWords = 2 * 2 * (kMaxCuts + 1) + 2;   // [stage][parity][segment] counters + [stage] overflow counters
@@ -445,6 +454,16 @@ static int alloc_queues(frt_renderer* r, uint32_t cap) {
     free_queues(r);
     r->qcap = cap;
     if (!stage_is_cut(r) || cap == 0) return FRT_OK;
+    if (r->wavefront) {
+        for (int st = 0; st < 2; ++st) {
+            for (int k = 0; k < 2; ++k) {
+                HIP_TRY(hipMalloc((void**)&r->d_wf_words[st][k], (size_t)44 * cap * sizeof(uint32_t)));
+                HIP_TRY(hipMalloc((void**)&r->d_wf_items[st][k], (size_t)2 * cap * sizeof(uint32_t)));
+            }
+            HIP_TRY(hipMalloc((void**)&r->d_wf_hits[st], (size_t)7 * cap * sizeof(uint32_t)));
+        }
+        return FRT_OK;
+    }
     const int nbuf = r->ncuts >= 2 ? 2 : 1;
     for (int st = 0; st < 2; ++st)
         for (int k = 0; k < nbuf; ++k)
@@ -504,6 +523,10 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
                 if (*p == ',') ++p; else break;
             }
         }
+        if (const char* e = getenv("FRT_WAVEFRONT")) {      // experiment knob: the ray-level wavefront needs the cut at depth 1
+            r->wavefront = atoi(e) != 0 && !(r->flags & FRT_FLAG_COMPACTION) && r->max_depth > 1 && r->max_depth < 31;
+            if (r->wavefront) { r->ncuts = 1; r->cuts[0] = 1; }
+        }
         r->qcap_max = r->W * std::min(r->H, (r->re - r->rb) + 2u * kHaloSpatial);   // every traced pixel parks
         // Default capacity from the share of paths that reach the first cut (Cornell Box, oracle counts per pixel: 0.65 / 0.50 / 0.11
         // alive at depth 1 / 2 / 3): generous, but not the worst case — a full queue is not an error (run_segment_and_park), and
@@ -515,6 +538,8 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         if (const char* e = getenv("FRT_QUEUE_CAP")) { const long v = atol(e); if (v > 0) { cap = std::min<uint32_t>((uint32_t)v, r->qcap_max); r->qcap_fixed = true; } }
         int rc = alloc_queues(r, cap);
         if (rc) return rc;
+        HIP_TRY(hipMalloc((void**)&r->d_wf_counts, 2 * kWfCounterWords * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(r->d_wf_counts, 0, 2 * kWfCounterWords * sizeof(uint32_t), r->stream));
         HIP_TRY(hipMalloc((void**)&r->d_qcount, kQcountWords * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(r->d_qcount, 0, kQcountWords * sizeof(uint32_t), r->stream));
         if (!getenv("FRT_NO_TILE_ORDER")) {   // (experiment knob: tile rows top to bottom)
@@ -537,6 +562,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         r->resident = false;
         if (const char* e = getenv("FRT_RESIDENT")) r->resident = atoi(e) != 0 && r->res_nodes > 0 && !(r->flags & FRT_FLAG_COMPACTION);
         if (const char* e = getenv("FRT_STREAM")) { r->stream_mode = atoi(e) != 0; if (atoi(e) > 1) r->shade_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: n > 1 = shade_min
+        if (const char* e = getenv("FRT_WG_PARK")) r->wg_park = atoi(e) != 0;
         if (const char* e = getenv("FRT_STREAM_SLICE")) r->stream_slice = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("FRT_REFILL")) { r->refill = atoi(e) != 0; if (atoi(e) > 1) r->refill_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: 0 off, 1 on, n > 1: refill when >= n lanes are free
         if (const char* e = getenv("FRT_RES_BATCH")) r->res_batch = (uint32_t)atoi(e);      // experiment knob: tiles per fetch (1, 2, 4)
@@ -587,6 +613,7 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
 // run beside the interior one); the continuation launches use the pairs behind them.
 static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, TraceLaunch& L, int work_slot = 0) {
     memset(&L, 0, sizeof(L));
+    L.wg_park = r->wg_park;
     L.refill = r->refill; L.refill_min = r->refill_min; L.stream = r->stream_mode; L.shade_min = r->shade_min; L.slice = r->stream_slice;
     L.resident = r->resident; L.res_nodes = r->res_nodes; L.res_tris = r->res_tris; L.num_cus = r->num_cus; L.res_batch = r->res_batch;
     L.work = r->d_work + ((size_t)(stage - 1) * kWorkSlots + (size_t)work_slot) * 2;
@@ -601,6 +628,15 @@ static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, Tr
     L.capacity = r->qcap;
     L.overflow = r->d_qcount + 2 * 2 * (kMaxCuts + 1) + (stage - 1);
     L.tile_state = (with_tile_state && r->d_tiles) ? r->d_tiles + (size_t)(stage - 1) * kTileStateWords : nullptr;
+    if (r->wavefront && cut) {
+        L.wavefront = true;
+        for (int k = 0; k < 2; ++k) { L.wf_words[k] = r->d_wf_words[stage - 1][k]; L.wf_items[k] = r->d_wf_items[stage - 1][k]; }
+        L.wf_hits = r->d_wf_hits[stage - 1];
+        L.qwords[0] = L.wf_words[0]; L.qwords[1] = nullptr;
+        L.counts = r->d_wf_counts + (size_t)(stage - 1) * kWfCounterWords;      // cleared by the host before the stage's pixel launch
+        L.zero_counts = nullptr;
+        L.slice = r->stream_slice;
+    }
 }
 
 // G-buffer + T-trace over their rows on stream `q`; pending_set >= 0: count the rays in that pending set (speculative work).
@@ -625,6 +661,7 @@ static int launch_g_and_trace(frt_renderer* r, FrameView fv, hipStream_t q, bool
         trace_launch_of(r, 1, true, L);
         frt_renderer::Timed t{};
         if (timed) { int rc = timer_begin(r, t, 1, q); if (rc) return rc; }
+        if (L.wavefront) HIP_TRY(hipMemsetAsync(L.counts, 0, kWfCounterWords * sizeof(uint32_t), q));
         HIP_TRY(launch_trace_pixels(1, r->sv, fv, q, L));
         if (trace_has_continuations(L, r->max_depth)) HIP_TRY(launch_trace_continuations(1, r->sv, fv, q, L));
         if (timed) { int rc = timer_end(r, t, q); if (rc) return rc; }
@@ -781,6 +818,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
             spatial_inner_rows(r, y0, y1, ia, ib);
             if ((sp & FRT_PHASE_SPATIAL_INNER) && !r->s_inner_done) {
                 trace_launch_of(r, 2, true, L);
+                if (L.wavefront) HIP_TRY(hipMemsetAsync(L.counts, 0, kWfCounterWords * sizeof(uint32_t), r->stream));   // (whole-frame renderers: the interior launch is the first of the stage)
                 fv.y0 = ia; fv.y1 = ib;
                 HIP_TRY(launch_trace_pixels(2, r->sv, fv, r->stream, L));
                 r->s_inner_done = true;

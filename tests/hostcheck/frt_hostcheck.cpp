@@ -43,7 +43,7 @@ static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned lo
     const uint32_t npix = h->W * h->H;
     std::vector<uint32_t> wa((size_t)kContWordsSpatial * npix), wb((size_t)kContWordsSpatial * npix);
     uint32_t ca = 0, cb = 0;
-    ContQueue qa{wa.data(), &ca, npix, nullptr}, qb{wb.data(), &cb, npix, nullptr};
+    ContQueue qa{wa.data(), &ca, npix, nullptr, 1u}, qb{wb.data(), &cb, npix, nullptr, 1u};
     uint32_t stack[kStackDepth];
     constexpr int V = STAGE == 1 ? 0 : 1;
     for (uint32_t pix = 0; pix < npix; ++pix) {
