@@ -192,8 +192,12 @@ def test_two_rank_strips_through_torch_distributed(gpu, tmp_path):
     # moving camera: motion halo of 6 rows, two exchanges per frame
     res = run_ranks("gpu", 2, tmp_path, ("--H", "96", "--W", "160", "--frames", "5", "--moving", "6"))
     assert res["ok"] and res["rays_all_ranks"] == res["oracle_rays"], res
-    # bench.py's configuration: 1080p, side-stream schedule (half-frame strips are cut: continuation on the side stream, post deferred)
+    # bench.py's configuration: 1080p, two-stream schedule (half-frame strips are cut; the next frame's G-buffer + T-trace run ahead)
     res = run_ranks("gpu", 2, tmp_path, ("--H", "1080", "--W", "1920", "--frames", "4", "--flags", "8"))
+    assert res["ok"] and res["rays_all_ranks"] == res["oracle_rays"], res
+    # the same with a MOVING camera (the "pre" rows — previous spatial reservoirs — and the accumulation rows must be complete when
+    # they are read for the exchange, whatever runs on the renderer's other streams): motion halo of 8 rows, speculation dropped every frame
+    res = run_ranks("gpu", 2, tmp_path, ("--H", "1080", "--W", "1920", "--frames", "4", "--flags", "8", "--moving", "8"))
     assert res["ok"] and res["rays_all_ranks"] == res["oracle_rays"], res
 
 
