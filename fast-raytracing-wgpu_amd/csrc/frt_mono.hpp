@@ -449,10 +449,11 @@ template <class Ctx>
 FRT_HD bool spatial_neighbors(Ctx& c, uint32_t pix, ReservoirView& r) {
     SpatialState ss;
     if (!spatial_begin(c, ss, pix)) return false;
+    const SpatialCentre centre = spatial_centre(c.fv, pix);
     while (ss.i < ss.n) {
         AnyReq req;
         req.want = false; req.o = splat3(0.0f); req.d = splat3(0.0f); req.tmin = 0.0f; req.tmax = 0.0f;
-        spatial_neighbor_prepare(c, ss, req);
+        spatial_neighbor_prepare(c, ss, req, centre);
         bool visible = true;
         if (req.want) visible = !c.any(req.o, req.d, req.tmin, req.tmax);
         spatial_neighbor_finish(ss, visible);

@@ -368,7 +368,21 @@ FRT_HD bool spatial_begin(PathCtx& c, SpatialState& ss, uint32_t pixel_idx) {
 }
 // One iteration of the neighbour loop up to its visibility ray (:912-982). Sets ss.pending when a candidate awaits the ray
 // result (req.want says whether a ray is actually needed).
-FRT_HD void spatial_neighbor_prepare(PathCtx& c, SpatialState& ss, AnyReq& req) {
+// The centre pixel's own G-buffer values: the same for every neighbour, decoded once per pixel by the kernels.
+struct SpatialCentre { f3 pos_w, normal, albedo, camera_pos; uint32_t mat_id; };
+FRT_HD SpatialCentre spatial_centre(const FrameView& fv, uint32_t pix) {
+    SpatialCentre k;
+    float4 pos_w4 = fv.gpos[pix];
+    k.pos_w = mk3(pos_w4.x, pos_w4.y, pos_w4.z);
+    float4 normal_w = fv.gnormal[pix];
+    k.normal = decode_octahedral_normal(normal_w.x, normal_w.y);
+    k.mat_id = (uint32_t)(pos_w4.w + 0.1f);
+    k.albedo = xyz(unpack_rgba8(fv.galbedo[pix]));
+    k.camera_pos = mk3(fv.cam.view_pos[0], fv.cam.view_pos[1], fv.cam.view_pos[2]);
+    return k;
+}
+template <class Ctx>
+FRT_HD void spatial_neighbor_prepare(Ctx& c, SpatialState& ss, AnyReq& req, const SpatialCentre& k) {
     const SceneView& sc = c.sc; const FrameView& fv = c.fv;
     ss.pending = false;
     uint32_t px = ss.pix % fv.W, py = ss.pix / fv.W;
@@ -385,13 +399,8 @@ FRT_HD void spatial_neighbor_prepare(PathCtx& c, SpatialState& ss, AnyReq& req) 
     uint32_t nidx = (uint32_t)ny * fv.W + (uint32_t)nx;
     float4 n_pos4 = fv.gpos[nidx];
     if (n_pos4.w < 0.0f) return;
-    float4 pos_w4 = fv.gpos[ss.pix];
-    f3 pos_w = mk3(pos_w4.x, pos_w4.y, pos_w4.z);
-    float4 normal_w = fv.gnormal[ss.pix];
-    f3 normal = decode_octahedral_normal(normal_w.x, normal_w.y);
-    uint32_t mat_id = (uint32_t)(pos_w4.w + 0.1f);
-    f3 albedo = xyz(unpack_rgba8(fv.galbedo[ss.pix]));
-    f3 camera_pos = mk3(fv.cam.view_pos[0], fv.cam.view_pos[1], fv.cam.view_pos[2]);
+    const f3 pos_w = k.pos_w, normal = k.normal, albedo = k.albedo, camera_pos = k.camera_pos;
+    const uint32_t mat_id = k.mat_id;
     f3 n_pos = mk3(n_pos4.x, n_pos4.y, n_pos4.z);
     float4 n_nrm = fv.gnormal[nidx];
     f3 n_normal = decode_octahedral_normal(n_nrm.x, n_nrm.y);
@@ -420,6 +429,9 @@ FRT_HD void spatial_neighbor_prepare(PathCtx& c, SpatialState& ss, AnyReq& req) 
     ss.cand_s_path = n_s_path;
     if (t_min >= t_max) return;   // "too close": treated as unoccluded without a ray
     req.want = true; req.o = pos_w; req.d = ray_dir; req.tmin = t_min; req.tmax = t_max;
+}
+FRT_HD void spatial_neighbor_prepare(PathCtx& c, SpatialState& ss, AnyReq& req) {
+    spatial_neighbor_prepare(c, ss, req, spatial_centre(c.fv, ss.pix));
 }
 FRT_HD void spatial_neighbor_finish(SpatialState& ss, bool visible) {
     if (ss.pending && visible)
