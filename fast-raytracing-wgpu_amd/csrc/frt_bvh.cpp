@@ -179,6 +179,82 @@ static void quantize_pair_nodes(SceneBuilder& b) {
     }
 }
 
+// Quad nodes: the canonical BVH2 with every other level folded away. Starting from the two children of an inner node, the inner child
+// with the largest surface area is replaced by its own two children until the node holds four children or only leaves: 2 to 4 children
+// per node, the same leaves (and triangle slots) as the pair tree, about half as many dependent node fetches per ray. Layout (32 floats):
+// lo.x[4], hi.x[4], lo.y[4], hi.y[4], lo.z[4], hi.z[4], reference[4], unused[4]; a reference is a quad node index or a leaf
+// (kLeafFlag | count << 24 | first slot); an empty slot holds a far-away degenerate box (misses every ray) and kNoChild. Nodes are numbered
+// breadth-first (the top of the tree is contiguous).
+// Traversal stack: a node with k children hit pushes k - 1 references, so a folded tree can need more entries than the binary one. A fold is
+// therefore only made while every inner child could still be finished as a plain binary subtree within kStackDepth entries (`used` = what the
+// ancestors may already have pushed): the quad tree of any scene the builder accepts (depth <= kMaxBvhDepth) fits the stack by construction.
+static void build_quad_nodes(SceneBuilder& b) {
+    b.quad_nodes.clear(); b.quad_stack_need = 0;
+    const std::vector<frt_bvh2_node>& t = b.bvh2;
+    const uint32_t budget = (uint32_t)kStackDepth - 1u;
+    std::vector<uint32_t> height(t.size(), 1u);          // levels of the binary subtree (a leaf = 1): children follow their parent in `t`
+    for (size_t i = t.size(); i-- > 0;)
+        if (t[i].count == 0) height[i] = 1u + std::max(height[t[i].left_first], height[t[i].left_first + 1]);
+    auto half_area = [&](uint32_t ni) {
+        const float dx = t[ni].bmax[0] - t[ni].bmin[0], dy = t[ni].bmax[1] - t[ni].bmin[1], dz = t[ni].bmax[2] - t[ni].bmin[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Kids { uint32_t c[4]; int n; };
+    auto fits = [&](const uint32_t* c, int n, uint32_t used) {
+        for (int i = 0; i < n; ++i)
+            if (t[c[i]].count == 0 && used + (uint32_t)(n - 1) + (height[c[i]] - 1u) > budget) return false;
+        return true;
+    };
+    auto children_of = [&](uint32_t ni, uint32_t used) -> Kids {
+        Kids k{};
+        if (t[ni].count > 0) { k.c[0] = ni; k.n = 1; return k; }       // a lone leaf root
+        k.n = 2; k.c[0] = t[ni].left_first; k.c[1] = t[ni].left_first + 1;
+        while (k.n < 4) {
+            int pick = -1; float best = -1.0f;
+            for (int i = 0; i < k.n; ++i) if (t[k.c[i]].count == 0 && half_area(k.c[i]) > best) { best = half_area(k.c[i]); pick = i; }
+            if (pick < 0) break;
+            Kids w = k;
+            for (int i = w.n; i > pick + 1; --i) w.c[i] = w.c[i - 1];
+            w.c[pick] = t[k.c[pick]].left_first; w.c[pick + 1] = t[k.c[pick]].left_first + 1;
+            ++w.n;
+            if (!fits(w.c, w.n, used)) break;
+            k = w;
+        }
+        return k;
+    };
+    std::vector<uint32_t> order(1, 0u), used(1, 0u), quad_of(t.size(), kNoChild);
+    std::vector<Kids> kids;
+    quad_of[0] = 0u;
+    for (size_t h = 0; h < order.size(); ++h) {
+        const Kids k = children_of(order[h], used[h]);
+        kids.push_back(k);
+        for (int i = 0; i < k.n; ++i)
+            if (t[k.c[i]].count == 0) { quad_of[k.c[i]] = (uint32_t)order.size(); order.push_back(k.c[i]); used.push_back(used[h] + (uint32_t)(k.n - 1)); }
+    }
+    b.quad_nodes.resize(order.size());
+    std::vector<uint32_t> need(order.size(), 0u);
+    for (size_t h = order.size(); h-- > 0;) {      // children have larger indices than their parent: bottom-up
+        const Kids& k = kids[h];
+        QuadNode q{};
+        uint32_t deepest = 0;
+        for (int i = 0; i < 4; ++i) {
+            uint32_t ref = kNoChild;
+            for (int a = 0; a < 3; ++a) q.q[8 * a + i] = q.q[8 * a + 4 + i] = 1.0e30f;   // empty slot: a far-away point, misses every ray (|1 / d| >= 1)
+            if (i < k.n) {
+                const frt_bvh2_node& c = t[k.c[i]];
+                for (int a = 0; a < 3; ++a) { q.q[8 * a + i] = c.bmin[a]; q.q[8 * a + 4 + i] = c.bmax[a]; }
+                if (c.count > 0) ref = kLeafFlag | (c.count << 24) | c.left_first;
+                else { ref = quad_of[k.c[i]]; deepest = std::max(deepest, need[ref]); }
+            }
+            memcpy(&q.q[24 + i], &ref, 4);
+        }
+        need[h] = (uint32_t)(k.n - 1) + deepest;
+        b.quad_nodes[h] = q;
+    }
+    b.quad_stack_need = need[0];
+    if (b.quad_stack_need > (uint32_t)kStackDepth) b.error = "quad tree exceeds the traversal stack";   // (cannot happen: see above)
+}
+
 void SceneBuilder::build_gpu_layout() {
     pair_nodes.clear(); tri_slots.clear(); instances_dev.clear(); shade_tris.clear();
     if (!error.empty()) return;
@@ -238,6 +314,7 @@ void SceneBuilder::build_gpu_layout() {
         }
     }
     quantize_pair_nodes(*this);
+    build_quad_nodes(*this);
     // shading records: the instance -> mesh -> index -> attribute chain of gbuffer.wgsl:129-145, flattened per triangle
     shade_tris.assign(tris.size(), ShadeTri{});
     for (size_t id = 0; id < tris.size(); ++id) {

@@ -143,6 +143,7 @@ static int upload_scene(frt_renderer* r, const SceneBuilder& b) {
     SceneView& sv = r->sv;
     int rc;
     if ((rc = upload(r, b.pair_nodes, &sv.nodes))) return rc;
+    if ((rc = upload(r, b.quad_nodes, &sv.nodes4))) return rc;
     if ((rc = upload(r, b.tri_slots, &sv.tris))) return rc;
     if ((rc = upload(r, b.qnode_a, &sv.qnode_a))) return rc;
     if ((rc = upload(r, b.qnode_b, &sv.qnode_b))) return rc;

@@ -64,6 +64,7 @@ struct TriRec { float v0[3], e1[3], e2[3]; };
 // ref: bit 31 clear -> pair-node index; bit 31 set -> leaf: bits 0..23 first triangle slot, bits 24..30 triangle count.
 // An absent child has ref = 0xFFFFFFFF and an inverted box.
 struct PairNode { float q[16]; };
+struct QuadNode { float q[32]; };   // frt_trace.hpp: trace4 (four child boxes per node, 128 B)
 // Triangle slot, 48 B, in leaf order: (v0.xyz, flattened id bits) (e1.xyz, instance index bits) (e2.xyz, 0)
 struct TriSlot { float q[12]; };
 // Shading record, 128 B per flattened triangle (frt_shade.hpp: fetch_hit_geometry)
@@ -107,6 +108,8 @@ public:
     std::vector<uint32_t> bvh2_tri_index;
     uint32_t bvh_depth = 0, bvh_leaves = 0, bvh_max_leaf = 0;
     std::vector<PairNode> pair_nodes;
+    std::vector<QuadNode> quad_nodes;       // the same tree with every other level folded away (build_quad_nodes)
+    uint32_t quad_stack_need = 0;           // deepest traversal stack a ray can need in the quad tree
     std::vector<uint32_t> qnode_a, qnode_b;     // quantized pair nodes, 4 words per node each (frt_trace.hpp: QBvh)
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     std::vector<TriSlot> tri_slots;

@@ -58,8 +58,9 @@ struct PathCtx {
     FRT_HD float rand() { rng = pcg_hash(rng); return (float)rng / 4294967296.0f; }   // restir.wgsl:138-141 (literal rounds to 2^32)
     // The two ray queries of the shaders (rayQueryInitialize ... rayQueryGetCommittedIntersection). Functions that trace are templates on
     // the context type and call these, so that a kernel can substitute its own traversal (frt_kernels.hip: ResidentCtx walks a BVH cached in LDS).
-    FRT_HD void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) { n_closest++; trace<false>(sc, o, d, tmin, tmax, stk, stride, h); }
-    FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) { HitRec h; n_any++; trace<true>(sc, o, d, tmin, tmax, stk, stride, h); return h.tri != 0xFFFFFFFFu; }
+    // Default: the quad tree (frt_trace.hpp: trace4).
+    FRT_HD void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) { n_closest++; trace4<false>(sc, o, d, tmin, tmax, stk, stride, h); }
+    FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) { HitRec h; n_any++; trace4<true>(sc, o, d, tmin, tmax, stk, stride, h); return h.tri != 0xFFFFFFFFu; }
 };
 
 FRT_HD float rand_lcg(uint32_t& state) {   // restir.wgsl:781-786
@@ -335,7 +336,7 @@ FRT_HD void gbuffer_pixel(PathCtx& c, uint32_t px, uint32_t py) {
     f3 direction = normalize(xyz(target) / target.w - origin);
     HitRec h;
     c.n_closest++;
-    trace<false>(sc, origin, direction, 0.001f, 1000.0f, c.stk, c.stride, h);
+    trace4<false>(sc, origin, direction, 0.001f, 1000.0f, c.stk, c.stride, h);
     if (h.tri == 0xFFFFFFFFu) {
         fv.gpos[pix] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
         fv.gnormal[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -43,6 +43,7 @@ struct SceneView {
     const uint4* qnode_a; const uint4* qnode_b;
     float qmin[3], qstep[3];
     uint32_t bvh_depth;
+    const float4* nodes4;       // quad nodes, 8 x float4 each (frt_bvh.cpp: build_quad_nodes): what the default kernels walk (trace4)
 };
 
 struct HitRec {
@@ -151,6 +152,88 @@ FRT_HD void trace(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint3
         uint32_t first = cur & 0x00FFFFFFu, count = (cur >> 24) & 0x7Fu;
         for (uint32_t k = 0; k < count; ++k) {
             const float4* tp = sc.tris + (size_t)(first + k) * 3u;
+            float4 a = tp[0], b = tp[1], c = tp[2];
+            float t, u, v, det;
+            if (intersect_tri(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, d, tmin, tmax, t, u, v, det)) {
+                uint32_t id = f2u(a.w);
+                if (ANY) { hit.tri = id; hit.t = t; return; }
+                if (t < hit.t || (t == hit.t && id < hit.tri)) {
+                    hit.t = t; hit.u = u; hit.v = v; hit.tri = id; hit.inst = f2u(b.w); best_det = det;
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = stk[(uint32_t)sp * stride];
+    }
+    if (!ANY && hit.tri != 0xFFFFFFFFu) {
+        bool front = best_det > 0.0f;
+        if (sc.instances[hit.inst].flip) front = !front;
+        hit.front = front;
+    }
+}
+
+// ---- quad nodes -----------------------------------------------------------------------------------------------------------------
+// Four child boxes per node (frt_bvh.cpp: build_quad_nodes): one dependent fetch (7 x 16 B) decides two levels of the binary tree, so a
+// ray takes about half as many node steps, each with four independent slab tests. Closest-hit rays visit the hit children near to far
+// (a five-exchange sorting network on (entry distance, reference)) — any-hit rays too: which triangles are hit does not depend on the
+// order (hit semantics above), but near-first finds an occluder sooner (slot order measured 10 % slower per traced stage).
+FRT_HD void slab4(const float4* n, f3 inv, f3 oinv, float tmin, float tlim, float t[4], bool h[4]) {
+    const float4 lx = n[0], hx = n[1], ly = n[2], hy = n[3], lz = n[4], hz = n[5];
+    const frt_v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const frt_v2f ox = {oinv.x, oinv.x}, oy = {oinv.y, oinv.y}, oz = {oinv.z, oinv.z};
+    const frt_v2f xl0 = __builtin_elementwise_fma(frt_v2f{lx.x, lx.y}, ix, ox), xl1 = __builtin_elementwise_fma(frt_v2f{lx.z, lx.w}, ix, ox);
+    const frt_v2f xh0 = __builtin_elementwise_fma(frt_v2f{hx.x, hx.y}, ix, ox), xh1 = __builtin_elementwise_fma(frt_v2f{hx.z, hx.w}, ix, ox);
+    const frt_v2f yl0 = __builtin_elementwise_fma(frt_v2f{ly.x, ly.y}, iy, oy), yl1 = __builtin_elementwise_fma(frt_v2f{ly.z, ly.w}, iy, oy);
+    const frt_v2f yh0 = __builtin_elementwise_fma(frt_v2f{hy.x, hy.y}, iy, oy), yh1 = __builtin_elementwise_fma(frt_v2f{hy.z, hy.w}, iy, oy);
+    const frt_v2f zl0 = __builtin_elementwise_fma(frt_v2f{lz.x, lz.y}, iz, oz), zl1 = __builtin_elementwise_fma(frt_v2f{lz.z, lz.w}, iz, oz);
+    const frt_v2f zh0 = __builtin_elementwise_fma(frt_v2f{hz.x, hz.y}, iz, oz), zh1 = __builtin_elementwise_fma(frt_v2f{hz.z, hz.w}, iz, oz);
+    const float xl[4] = {xl0.x, xl0.y, xl1.x, xl1.y}, xh[4] = {xh0.x, xh0.y, xh1.x, xh1.y};
+    const float yl[4] = {yl0.x, yl0.y, yl1.x, yl1.y}, yh[4] = {yh0.x, yh0.y, yh1.x, yh1.y};
+    const float zl[4] = {zl0.x, zl0.y, zl1.x, zl1.y}, zh[4] = {zh0.x, zh0.y, zh1.x, zh1.y};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float tn = fmaxn(fmaxn(fminn(xl[c], xh[c]), fminn(yl[c], yh[c])), fmaxn(fminn(zl[c], zh[c]), tmin));
+        const float tf = fminn(fminn(fmaxn(xl[c], xh[c]), fmaxn(yl[c], yh[c])), fminn(fmaxn(zl[c], zh[c]), tlim));
+        t[c] = tn;
+        h[c] = tn <= tf * 1.0000004f;
+    }
+}
+template <bool ANY>
+FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint32_t* stk, uint32_t stride, HitRec& hit) {
+    hit.t = tmax; hit.tri = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f; hit.inst = 0u; hit.front = false;
+    float best_det = 0.0f;
+    f3 inv = mk3(prune_rcp(d.x), prune_rcp(d.y), prune_rcp(d.z));
+    f3 oinv = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    const uint32_t kDone = 0xFFFFFFFFu;
+    const float kFar = 3.0e38f;
+    int sp = 0;
+    uint32_t cur = 0u;   // quad node 0 is the root
+    for (;;) {
+        while (!(cur & 0x80000000u)) {
+            const float4* n = sc.nodes4 + (size_t)cur * 8u;
+            const float4 rf = n[6];
+            float t[4]; bool h[4];
+            slab4(n, inv, oinv, tmin, ANY ? tmax : hit.t, t, h);
+            uint32_t r[4] = {f2u(rf.x), f2u(rf.y), f2u(rf.z), f2u(rf.w)};
+            // (an empty slot holds a far-away degenerate box: it never passes the slab test, no reference check needed)
+            float k[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) k[c] = h[c] ? t[c] : kFar;
+#define FRT_CE(a, b) { const bool s_ = k[b] < k[a]; const float ka_ = s_ ? k[b] : k[a], kb_ = s_ ? k[a] : k[b]; \
+                       const uint32_t ra_ = s_ ? r[b] : r[a], rb_ = s_ ? r[a] : r[b]; k[a] = ka_; k[b] = kb_; r[a] = ra_; r[b] = rb_; }
+            FRT_CE(0, 1) FRT_CE(2, 3) FRT_CE(0, 2) FRT_CE(1, 3) FRT_CE(1, 2)
+#undef FRT_CE
+            if (k[3] < kFar) { stk[(uint32_t)sp * stride] = r[3]; ++sp; }
+            if (k[2] < kFar) { stk[(uint32_t)sp * stride] = r[2]; ++sp; }
+            if (k[1] < kFar) { stk[(uint32_t)sp * stride] = r[1]; ++sp; }
+            if (k[0] < kFar) cur = r[0];
+            else if (sp == 0) cur = kDone;
+            else { --sp; cur = stk[(uint32_t)sp * stride]; }
+        }
+        if (cur == kDone) break;
+        uint32_t first = cur & 0x00FFFFFFu, count = (cur >> 24) & 0x7Fu;
+        for (uint32_t kk = 0; kk < count; ++kk) {
+            const float4* tp = sc.tris + (size_t)(first + kk) * 3u;
             float4 a = tp[0], b = tp[1], c = tp[2];
             float t, u, v, det;
             if (intersect_tri(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, d, tmin, tmax, t, u, v, det)) {

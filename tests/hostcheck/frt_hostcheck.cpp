@@ -95,6 +95,7 @@ void* hc_create(const frt_scene* s, uint32_t W, uint32_t H, uint32_t max_depth, 
     for (auto& l : b.data_textures) h->data_tex.insert(h->data_tex.end(), l.begin(), l.end());
     SceneView& sv = h->sv;
     sv.nodes = reinterpret_cast<const float4*>(b.pair_nodes.data());
+    sv.nodes4 = reinterpret_cast<const float4*>(b.quad_nodes.data());
     sv.tris = reinterpret_cast<const float4*>(b.tri_slots.data());
     sv.shade_tris = reinterpret_cast<const float4*>(b.shade_tris.data());
     sv.instances = reinterpret_cast<const InstanceView*>(b.instances_dev.data());
@@ -186,12 +187,13 @@ int hc_read(void* p, int buf, int index, void* out) {
 void hc_rays(void* p, unsigned long long out[2]) { out[0] = ((HostCheck*)p)->rays[0]; out[1] = ((HostCheck*)p)->rays[1]; }
 
 // probe: closest / any hits through the product traversal. quantized = 0: float pair nodes (trace), 1: the 16-bit pair nodes the
-// resident kernels cache in LDS (trace_q), here over host arrays
+// resident kernels cache in LDS (trace_q), here over host arrays, 2: quad nodes (trace4)
 void hc_trace(const frt_scene* s, int any, uint32_t n, const float* o, const float* d, float tmin, const float* tmax,
               float* t_out, uint32_t* tri_out, float* uv_out, uint8_t* front_out, int quantized) {
     const SceneBuilder& b = s->b;
     SceneView sv{};
     sv.nodes = reinterpret_cast<const float4*>(b.pair_nodes.data());
+    sv.nodes4 = reinterpret_cast<const float4*>(b.quad_nodes.data());
     sv.tris = reinterpret_cast<const float4*>(b.tri_slots.data());
     sv.instances = reinterpret_cast<const InstanceView*>(b.instances_dev.data());
     QBvh qb;
@@ -201,7 +203,8 @@ void hc_trace(const frt_scene* s, int any, uint32_t n, const float* o, const flo
     for (uint32_t i = 0; i < n; ++i) {
         HitRec h;
         f3 oo = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-        if (quantized) { if (any) trace_q<true>(sv, qb, oo, dd, tmin, tmax[i], stack, 1u, h); else trace_q<false>(sv, qb, oo, dd, tmin, tmax[i], stack, 1u, h); }
+        if (quantized == 2) { if (any) trace4<true>(sv, oo, dd, tmin, tmax[i], stack, 1u, h); else trace4<false>(sv, oo, dd, tmin, tmax[i], stack, 1u, h); }
+        else if (quantized) { if (any) trace_q<true>(sv, qb, oo, dd, tmin, tmax[i], stack, 1u, h); else trace_q<false>(sv, qb, oo, dd, tmin, tmax[i], stack, 1u, h); }
         else if (any) trace<true>(sv, oo, dd, tmin, tmax[i], stack, 1u, h);
         else trace<false>(sv, oo, dd, tmin, tmax[i], stack, 1u, h);
         t_out[i] = h.tri != 0xFFFFFFFFu ? h.t : -1.0f;

@@ -47,14 +47,15 @@ def test_bvh_equals_bruteforce(frt, orc, hostcheck, which):
         tv, iv, uvv, fv, st = os_.trace_closest(o, d, tmin, tmax, True)          # oracle walk of the imported BVH2
         th, ih, uvh, fh = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=False)   # product traversal (pair nodes), host build
         tq, iq, uvq, fq = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=False, quantized=True)   # ... over the 16-bit pair nodes of the resident kernels
-        for (t, i, uv, f) in ((tv, iv, uvv, fv), (th, ih, uvh, fh), (tq, iq, uvq, fq)):
+        t4, i4, uv4, f4 = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=False, quantized=2)      # ... over the quad nodes (four children per node)
+        for (t, i, uv, f) in ((tv, iv, uvv, fv), (th, ih, uvh, fh), (tq, iq, uvq, fq), (t4, i4, uv4, f4)):
             assert np.array_equal(i, ib) and np.array_equal(t, tb)
             hit = ib != 0xFFFFFFFF
             assert np.array_equal(uv[hit], uvb[hit]) and np.array_equal(f[hit], fb[hit])
         assert (ib != 0xFFFFFFFF).mean() > (0.2 if tmax > 1 else 0.02)
         ob = os_.trace_any(o, d, tmin, tmax, False)
         assert np.array_equal(os_.trace_any(o, d, tmin, tmax, True), ob)
-        for quantized in (False, True):
+        for quantized in (False, True, 2):
             _, ia, _, _ = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=True, quantized=quantized)
             assert np.array_equal((ia != 0xFFFFFFFF).astype(np.uint8), ob)
         assert np.array_equal(ob.astype(bool), tb >= 0)                           # any-hit <=> a closest hit exists
@@ -68,7 +69,7 @@ def test_in_plane_reconnection_rays_are_not_lost(frt, orc, hostcheck):
     d = np.array([[-0.76039785, 0, -0.64945745], [-0.08538333, 0, -0.9963482], [-0.3049969, 0, -0.95235336], [-0.8957124, 0, -0.4446341]], np.float32)
     tmax = np.array([0.32927045, 0.03921813, 0.026023595, 0.24082603], np.float32)
     want = os_.trace_any(o, d, 0.0001, tmax, False)
-    for quantized in (False, True):
+    for quantized in (False, True, 2):
         _, tri, _, _ = hostcheck.trace(fs, o, d, 0.0001, tmax, any_hit=True, quantized=quantized)
         assert np.array_equal((tri != 0xFFFFFFFF).astype(np.uint8), want)
 
