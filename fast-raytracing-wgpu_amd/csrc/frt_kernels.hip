@@ -1057,7 +1057,7 @@ __global__ void __launch_bounds__(kBlock) post_jitter_kernel(FrameView fv) {
 static dim3 grid_for(const FrameView& fv) { return dim3((fv.W + 15u) / 16u, (fv.y1 - fv.y0 + 15u) / 16u, 1u); }
 static bool empty_rows(const FrameView& fv) { return fv.y1 <= fv.y0 || fv.W == 0u; }
 static ContQueue queue_of(const TraceLaunch& L, uint32_t k) {
-    ContQueue q; q.words = L.qwords[k & 1u]; q.count = L.counts + k; q.capacity = L.capacity; q.overflow = L.overflow; q.nsub = L.wavefront ? (uint32_t)kWfSub : 1u; return q;
+    ContQueue q; q.words = L.qwords[k & 1u]; q.count = L.counts + k; q.capacity = (k & 1u) ? L.capacity_odd : L.capacity; q.overflow = L.overflow; q.nsub = L.wavefront ? (uint32_t)kWfSub : 1u; return q;
 }
 static uint32_t first_cut(const TraceLaunch& L, const FrameView& fv) { return L.ncuts ? L.cuts[0] : fv.max_depth; }
 
@@ -1155,8 +1155,8 @@ hipError_t launch_trace_continuations(int stage, const SceneView& sc, const Fram
         else hipLaunchKernelGGL(bounce_kernel<2>, dim3(wgs), dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), L.counts + 1, L.cuts[0], L.refill_min);
         return hipGetLastError();
     }
-    const dim3 cgrid((L.capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
     for (uint32_t k = 0; k < L.ncuts && L.cuts[k] < fv.max_depth; ++k) {
+        const dim3 cgrid((queue_of(L, k).capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
         const uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
         if (L.resident) {
             ResidentArgs ra{L.res_nodes, L.res_tris ? 1u : 0u, L.work + 2u * (3u + k), 1u};      // behind the three pixel-launch pairs (L.work = the stage's slot 0)

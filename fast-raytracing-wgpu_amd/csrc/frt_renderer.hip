@@ -81,10 +81,11 @@ struct frt_renderer {
     // continuation queues: per traced stage one word buffer per path segment parity (the second only with two cuts or more)
     uint32_t* d_qwords[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     uint32_t qcap = 0, qcap_max = 0;       // slots per queue; upper bound = every traced pixel parks
+    uint32_t qcap_odd = 0;                 // slots of the second word buffer (segments 1, 3: the survivors of two cuts)
     bool qcap_fixed = false;               // capacity given by the caller: never grown
     uint32_t* d_qcount = nullptr;          // [stage 1|2][launch parity 0|1][kMaxCuts + 1] counters, then [stage] overflow counters
     uint32_t qparity[2] = {0, 0};
-    uint32_t ncuts = 1, cuts[kMaxCuts] = {3, 0, 0, 0};   // measured best on the Cornell Box
+    uint32_t ncuts = 2, cuts[kMaxCuts] = {3, 5, 0, 0};   // measured best on the Cornell Box
     uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state, or null
     bool wg_park = true;                   // pixel kernels reserve queue slots once per workgroup (FRT_WG_PARK=0: once per wave, experiment knob)
     bool wavefront = false;                // ray-level wavefront (FRT_WAVEFRONT=1): per bounce depth a trace launch and a shade launch
@@ -465,10 +466,13 @@ static int alloc_queues(frt_renderer* r, uint32_t cap) {
         }
         return FRT_OK;
     }
+    // The second buffer holds what survives from the first cut to the second (Cornell Box, cuts 3 and 5: a fifth of the parked paths);
+    // like the first it may overflow (paths finish in place) and is grown with it.
     const int nbuf = r->ncuts >= 2 ? 2 : 1;
+    r->qcap_odd = (cap >= r->qcap_max) ? cap : std::min(cap, std::max(4096u, (uint32_t)(0.3 * cap)));
     for (int st = 0; st < 2; ++st)
         for (int k = 0; k < nbuf; ++k)
-            HIP_TRY(hipMalloc((void**)&r->d_qwords[st][k], (size_t)(st == 0 ? kContWordsPath : kContWordsSpatial) * cap * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&r->d_qwords[st][k], (size_t)(st == 0 ? kContWordsPath : kContWordsSpatial) * (k ? r->qcap_odd : cap) * sizeof(uint32_t)));
     return FRT_OK;
 }
 static int init_tile_state(frt_renderer* r) {
@@ -509,9 +513,10 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     }
     HIP_TRY(hipMalloc((void**)&r->d_counters, C_COUNT * sizeof(unsigned long long)));
     {   // the bounce depths at which paths are cut, and the continuation queues
-        // Parking pays when the launch saturates the chip (>= ~0.6 M pixels: +6 % at 1080p, +5 % at half a frame); a thin strip
-        // is bound by the latency of its longest path and the extra launch only adds to it (tools/strip_time.py), so thin strips run uncut.
-        if ((size_t)r->W * (r->re - r->rb) < 600000u) r->ncuts = 0;
+        // Measured with the quad-tree kernels (tools/strip_time.py, tools/cut_sweep.sh): a 1080p frame 2.57 ms uncut, 2.09 cut at depth 3,
+        // 2.00 cut at 3 and 5; half a frame 1.41 / 1.14 / 1.16; a quarter 0.76 / 0.66; an eighth 0.61 / 0.55. The second cut pays once the
+        // launch fills the chip several times over; a strip gets the first one only.
+        if ((size_t)r->W * (r->re - r->rb) < 1500000u) r->ncuts = 1;
         if (const char* e = getenv("FRT_CUTS")) {   // experiment knob: comma-separated ascending depths, "0" = never cut
             r->ncuts = 0;
             uint32_t last = 0;
@@ -566,6 +571,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         if (const char* e = getenv("FRT_WG_PARK")) r->wg_park = atoi(e) != 0;
         if (const char* e = getenv("FRT_STREAM_SLICE")) r->stream_slice = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("FRT_REFILL")) { r->refill = atoi(e) != 0; if (atoi(e) > 1) r->refill_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: 0 off, 1 on, n > 1: refill when >= n lanes are free
+        if ((r->refill || r->stream_mode) && !getenv("FRT_CUTS") && r->ncuts > 1) r->ncuts = 1;   // (those kernels replace the continuation launches of a single cut)
         if (const char* e = getenv("FRT_RES_BATCH")) r->res_batch = (uint32_t)atoi(e);      // experiment knob: tiles per fetch (1, 2, 4)
         if (const char* e = getenv("FRT_RES_TRIS")) { if (atoi(e) == 0) r->res_tris = false; }   // experiment knob: triangles from L2
         HIP_TRY(hipMalloc((void**)&r->d_work, kWorkWords * sizeof(uint32_t)));
@@ -626,7 +632,7 @@ static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, Tr
     uint32_t* base = r->d_qcount + (size_t)(stage - 1) * 2 * (kMaxCuts + 1);
     L.counts = base + (size_t)par * (kMaxCuts + 1);
     L.zero_counts = cut ? base + (size_t)(par ^ 1u) * (kMaxCuts + 1) : nullptr;
-    L.capacity = r->qcap;
+    L.capacity = r->qcap; L.capacity_odd = r->qcap_odd;
     L.overflow = r->d_qcount + 2 * 2 * (kMaxCuts + 1) + (stage - 1);
     L.tile_state = (with_tile_state && r->d_tiles) ? r->d_tiles + (size_t)(stage - 1) * kTileStateWords : nullptr;
     if (r->wavefront && cut) {
