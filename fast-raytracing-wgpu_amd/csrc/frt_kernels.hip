@@ -1156,7 +1156,8 @@ hipError_t launch_trace_continuations(int stage, const SceneView& sc, const Fram
         return hipGetLastError();
     }
     for (uint32_t k = 0; k < L.ncuts && L.cuts[k] < fv.max_depth; ++k) {
-        const dim3 cgrid((queue_of(L, k).capacity + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
+        const uint32_t gslots = std::max(queue_of(L, k).capacity, L.grid_min_slots);   // (workgroups beyond the queue's fill retire at once)
+        const dim3 cgrid((gslots + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
         const uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
         if (L.resident) {
             ResidentArgs ra{L.res_nodes, L.res_tris ? 1u : 0u, L.work + 2u * (3u + k), 1u};      // behind the three pixel-launch pairs (L.work = the stage's slot 0)

@@ -9,7 +9,7 @@ namespace frt {
 // later starts from slot 0. `zero_counts`: the counter set of this stage's NEXT launch, cleared in passing by the pixel kernel.
 // `tile_state`: the stage's sweep-direction state (frt_kernels.hip: TileOrder) or null = tile rows top to bottom.
 static constexpr int kMaxCuts = 4;
-struct TraceLaunch { uint32_t ncuts; uint32_t cuts[kMaxCuts]; uint32_t* qwords[2]; uint32_t* counts; uint32_t capacity, capacity_odd; uint32_t* overflow;   // capacity_odd: slots of qwords[1] (the odd segments: far fewer paths get that far)
+struct TraceLaunch { uint32_t ncuts; uint32_t cuts[kMaxCuts]; uint32_t* qwords[2]; uint32_t* counts; uint32_t capacity, capacity_odd, grid_min_slots; uint32_t* overflow;   // capacity_odd: slots of qwords[1] (the odd segments: far fewer paths get that far); grid_min_slots: the continuation grids cover at least this many slots
                      uint32_t* zero_counts; uint32_t* tile_state;
                      // resident form (frt_kernels.hip: resident_*_kernel): BVH cached in LDS, persistent workgroups
                      bool wg_park;   // pixel kernel: one queue reservation per workgroup instead of one per wave

@@ -81,11 +81,12 @@ struct frt_renderer {
     // continuation queues: per traced stage one word buffer per path segment parity (the second only with two cuts or more)
     uint32_t* d_qwords[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     uint32_t qcap = 0, qcap_max = 0;       // slots per queue; upper bound = every traced pixel parks
-    uint32_t qcap_odd = 0;                 // slots of the second word buffer (segments 1, 3: the survivors of two cuts)
+    uint32_t qslots[2][2] = {{0, 0}, {0, 0}};   // slots of each word buffer [stage][first | second buffer], derived from qcap (alloc_queues)
+    uint64_t qbytes = 0;                   // device bytes of the word buffers
     bool qcap_fixed = false;               // capacity given by the caller: never grown
     uint32_t* d_qcount = nullptr;          // [stage 1|2][launch parity 0|1][kMaxCuts + 1] counters, then [stage] overflow counters
     uint32_t qparity[2] = {0, 0};
-    uint32_t ncuts = 2, cuts[kMaxCuts] = {3, 5, 0, 0};   // measured best on the Cornell Box
+    uint32_t ncuts = 2, cuts[kMaxCuts] = {3, 4, 0, 0};   // measured best on the Cornell Box
     uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state, or null
     bool wg_park = true;                   // pixel kernels reserve queue slots once per workgroup (FRT_WG_PARK=0: once per wave, experiment knob)
     bool wavefront = false;                // ray-level wavefront (FRT_WAVEFRONT=1): per bounce depth a trace launch and a shade launch
@@ -457,6 +458,7 @@ static int alloc_queues(frt_renderer* r, uint32_t cap) {
     r->qcap = cap;
     if (!stage_is_cut(r) || cap == 0) return FRT_OK;
     if (r->wavefront) {
+        for (auto& q : r->qslots) q[0] = q[1] = cap;
         for (int st = 0; st < 2; ++st) {
             for (int k = 0; k < 2; ++k) {
                 HIP_TRY(hipMalloc((void**)&r->d_wf_words[st][k], (size_t)44 * cap * sizeof(uint32_t)));
@@ -466,13 +468,21 @@ static int alloc_queues(frt_renderer* r, uint32_t cap) {
         }
         return FRT_OK;
     }
-    // The second buffer holds what survives from the first cut to the second (Cornell Box, cuts 3 and 5: a fifth of the parked paths);
-    // like the first it may overflow (paths finish in place) and is grown with it.
+    // `cap` is the first buffer of the spatial stage. Measured per pixel on the Cornell Box (FRT_DEBUG_QUEUES; cuts 3 and 4): the spatial stage
+    // parks 0.165 paths at the first cut and 0.10 at the second, T-trace 0.108 and 0.049. The other three buffers are sized in that
+    // proportion (x 1.0 / 0.6 / 0.65 / 0.3 of `cap`, itself 0.25 per pixel by default); any of them may overflow (paths finish in place) and
+    // they are grown together. A capacity given by the caller applies to all four.
     const int nbuf = r->ncuts >= 2 ? 2 : 1;
-    r->qcap_odd = (cap >= r->qcap_max) ? cap : std::min(cap, std::max(4096u, (uint32_t)(0.3 * cap)));
+    static const double kShare[2][2] = {{0.65, 0.3}, {1.0, 0.6}};
+    r->qbytes = 0;
     for (int st = 0; st < 2; ++st)
-        for (int k = 0; k < nbuf; ++k)
-            HIP_TRY(hipMalloc((void**)&r->d_qwords[st][k], (size_t)(st == 0 ? kContWordsPath : kContWordsSpatial) * (k ? r->qcap_odd : cap) * sizeof(uint32_t)));
+        for (int k = 0; k < 2; ++k) {
+            r->qslots[st][k] = (r->qcap_fixed || cap >= r->qcap_max) ? cap : std::min(cap, std::max(4096u, (uint32_t)(kShare[st][k] * cap)));
+            if (k >= nbuf) continue;
+            const size_t bytes = (size_t)(st == 0 ? kContWordsPath : kContWordsSpatial) * r->qslots[st][k] * sizeof(uint32_t);
+            HIP_TRY(hipMalloc((void**)&r->d_qwords[st][k], bytes));
+            r->qbytes += bytes;
+        }
     return FRT_OK;
 }
 static int init_tile_state(frt_renderer* r) {
@@ -514,7 +524,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     HIP_TRY(hipMalloc((void**)&r->d_counters, C_COUNT * sizeof(unsigned long long)));
     {   // the bounce depths at which paths are cut, and the continuation queues
         // Measured with the quad-tree kernels (tools/strip_time.py, tools/cut_sweep.sh): a 1080p frame 2.57 ms uncut, 2.09 cut at depth 3,
-        // 2.00 cut at 3 and 5; half a frame 1.41 / 1.14 / 1.16; a quarter 0.76 / 0.66; an eighth 0.61 / 0.55. The second cut pays once the
+        // 2.00 cut at 3 and 5, 1.96 at 3 and 4; half a frame 1.41 / 1.14 / 1.16; a quarter 0.76 / 0.66; an eighth 0.61 / 0.55. The second cut pays once the
         // launch fills the chip several times over; a strip gets the first one only.
         if ((size_t)r->W * (r->re - r->rb) < 1500000u) r->ncuts = 1;
         if (const char* e = getenv("FRT_CUTS")) {   // experiment knob: comma-separated ascending depths, "0" = never cut
@@ -548,7 +558,9 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         HIP_TRY(hipMemsetAsync(r->d_wf_counts, 0, 2 * kWfCounterWords * sizeof(uint32_t), r->stream));
         HIP_TRY(hipMalloc((void**)&r->d_qcount, kQcountWords * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(r->d_qcount, 0, kQcountWords * sizeof(uint32_t), r->stream));
-        if (!getenv("FRT_NO_TILE_ORDER")) {   // (experiment knob: tile rows top to bottom)
+        // Sweep direction of the tile rows (frt_kernels.hip: TileOrder): paid 2 % with round 1's kernels on one stream; with the quad-tree kernels
+        // it costs 1-2 % on one stream and on two (2.39 vs 2.34, 2.00 vs 1.97 ms), so tile rows run top to bottom unless FRT_TILE_ORDER=1.
+        if (const char* e = getenv("FRT_TILE_ORDER"); e && atoi(e) != 0) {
             HIP_TRY(hipMalloc((void**)&r->d_tiles, 2 * kTileStateWords * sizeof(uint32_t)));
             rc = init_tile_state(r);
             if (rc) return rc;
@@ -632,7 +644,13 @@ static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, Tr
     uint32_t* base = r->d_qcount + (size_t)(stage - 1) * 2 * (kMaxCuts + 1);
     L.counts = base + (size_t)par * (kMaxCuts + 1);
     L.zero_counts = cut ? base + (size_t)(par ^ 1u) * (kMaxCuts + 1) : nullptr;
-    L.capacity = r->qcap; L.capacity_odd = r->qcap_odd;
+    L.capacity = r->qslots[stage - 1][0]; L.capacity_odd = r->qslots[stage - 1][1];
+    // Two streams: the spatial continuation launches (main stream) get a grid over half the stage's pixels, whatever the queue holds; the
+    // surplus workgroups retire at once. Measured 1.97 -> 1.92 ms per 1080p frame (grid of 0.6 / 0.8 / 1.0 / 2 / 4 M slots: 1.98 / 1.95 /
+    // 1.92 / 1.92 / 1.92; no effect on one stream, none for the T-trace launches on the ahead stream): while the grid is still being
+    // dispatched the main stream keeps its turn at the dispatcher beside the next frame's T-trace pixel kernel (profiles/r2_schedule_notes.md).
+    L.grid_min_slots = (stage == 2 && r->pipeline()) ? (uint32_t)std::min<uint64_t>(r->qcap_max, (uint64_t)r->W * (r->re - r->rb) / 2u) : 0u;
+    if (const char* e = getenv("FRT_CONT_GRID")) L.grid_min_slots = (uint32_t)atol(e);   // experiment knob
     L.overflow = r->d_qcount + 2 * 2 * (kMaxCuts + 1) + (stage - 1);
     L.tile_state = (with_tile_state && r->d_tiles) ? r->d_tiles + (size_t)(stage - 1) * kTileStateWords : nullptr;
     if (r->wavefront && cut) {
@@ -1027,6 +1045,13 @@ int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
     // queues that overflowed since the last call (paths were finished in place, nothing was lost): grow them while the GPU is idle
     uint32_t ov[2] = {0, 0};
     HIP_TRY(hipMemcpy(ov, r->d_qcount + 2 * 2 * (kMaxCuts + 1), sizeof(ov), hipMemcpyDeviceToHost));
+    if (getenv("FRT_DEBUG_QUEUES")) {   // (debug: the queue counters of the last launches, [stage][parity][segment])
+        uint32_t qc[kQcountWords];
+        HIP_TRY(hipMemcpy(qc, r->d_qcount, sizeof(qc), hipMemcpyDeviceToHost));
+        fprintf(stderr, "queues slots T %u %u S %u %u:", r->qslots[0][0], r->qslots[0][1], r->qslots[1][0], r->qslots[1][1]);
+        for (size_t i = 0; i < kQcountWords; ++i) fprintf(stderr, " %u", qc[i]);
+        fprintf(stderr, "\n");
+    }
     if (ov[0] || ov[1]) {
         r->stats.queue_overflow += (uint64_t)ov[0] + ov[1];
         HIP_TRY(hipMemset(r->d_qcount + 2 * 2 * (kMaxCuts + 1), 0, sizeof(ov)));
@@ -1036,6 +1061,7 @@ int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
         }
     }
     r->stats.queue_capacity = r->qcap;
+    r->stats.queue_bytes = r->qbytes;
     *out = r->stats;
     return FRT_OK;
 }

@@ -40,7 +40,7 @@ class Stats(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("frames", C.c_uint64),
                 ("ms_stage", C.c_double * 4), ("launches", C.c_uint64 * 4), ("rays_stage", (C.c_uint64 * 2) * 4), ("halo_overflow", C.c_uint64),
                 ("ms_merge", C.c_double), ("queue_overflow", C.c_uint64), ("queue_capacity", C.c_uint64),
-                ("speculated_frames", C.c_uint64), ("discarded_speculations", C.c_uint64)]
+                ("speculated_frames", C.c_uint64), ("discarded_speculations", C.c_uint64), ("queue_bytes", C.c_uint64)]
 
 
 assert C.sizeof(VertexAttr) == 32 and C.sizeof(Material) == 64 and C.sizeof(Light) == 64 and C.sizeof(CameraUniform) == 288

@@ -117,5 +117,5 @@ class Renderer:
         return {"rays_closest": s.rays_closest, "rays_any": s.rays_any, "frames": s.frames,
                 "ms_stage": list(s.ms_stage), "launches": list(s.launches),
                 "rays_stage": [[int(s.rays_stage[i][0]), int(s.rays_stage[i][1])] for i in range(4)], "halo_overflow": int(s.halo_overflow),
-                "ms_merge": s.ms_merge, "queue_overflow": int(s.queue_overflow), "queue_capacity": int(s.queue_capacity),
+                "ms_merge": s.ms_merge, "queue_overflow": int(s.queue_overflow), "queue_capacity": int(s.queue_capacity), "queue_bytes": int(s.queue_bytes),
                 "speculated_frames": int(s.speculated_frames), "discarded_speculations": int(s.discarded_speculations)}

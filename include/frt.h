@@ -214,9 +214,10 @@ typedef struct frt_stats {
     uint64_t halo_overflow;   /* strips: previous-frame reads (reprojection, history) outside own rows +- motion_halo_rows; 0 for a whole frame */
     double ms_merge;          /* summed T-merge kernel time (ms_stage[1] is T-trace); FRT_FLAG_TIMING only */
     uint64_t queue_overflow;  /* paths that found their continuation queue full and were finished in place */
-    uint64_t queue_capacity;  /* current slots per continuation queue */
+    uint64_t queue_capacity;  /* current slots of the largest continuation queue (the spatial stage's first); the others are sized in proportion */
     uint64_t speculated_frames;       /* FRT_FLAG_PIPELINE: frames whose G-buffer + T-trace ran ahead and were adopted */
     uint64_t discarded_speculations;  /* ... and speculated work that did not match the next camera and was dropped */
+    uint64_t queue_bytes;     /* device bytes of all continuation queues at the current capacity */
 } frt_stats;
 
 uint64_t frt_renderer_arena_bytes(uint32_t width, uint32_t height);
