@@ -28,7 +28,9 @@ frames = launches.get("merge_kernel") or (max(launches.values()) if launches els
 kern = {}
 for k, v in tab.items():
     e = dict(v)
-    e["launches_per_frame"] = min(1.0, launches[k] / frames) if frames else 0       # (the last speculated G-buffer + T-trace have no frame of their own)
+    lp = launches[k] / frames if frames else 0
+    # one launch per frame (the last speculated G-buffer + T-trace have no frame of their own); the continuation kernels run once per cut
+    e["launches_per_frame"] = float(round(lp)) if lp > 1.2 else min(1.0, lp)
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         e["hbm_bytes"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024       # gfx950: FETCH_SIZE counts 2 x 32 B units per KiB reported (MI355X_MICROARCH.md §HBM)
     if "SQ_THREAD_CYCLES_VALU" in v and v.get("SQ_ACTIVE_INST_VALU"):
