@@ -16,9 +16,15 @@ class HostCheck:
         L.hc_rays.argtypes = [P, P]
         L.hc_set_jitter.argtypes = [P, C.c_float, C.c_float]
         L.hc_trace.argtypes = [P, C.c_int, U32, P, P, C.c_float, P, P, P, P, P, C.c_int]
+        L.hc_quad_stats.argtypes = [P, P]
 
     def renderer(self, scene, w, h, max_depth=8, nthreads=8, state_machine=False):
         return HcRenderer(self, scene, w, h, max_depth, nthreads, state_machine)
+
+    def quad_stats(self, scene):
+        out = (C.c_uint32 * 6)()
+        self.L.hc_quad_stats(scene._h, out)
+        return dict(zip(("nodes", "stack_need", "stack_walked", "leaves", "triangles", "children_x100"), list(out)))
 
     def trace(self, scene, o, d, tmin, tmax, any_hit=False, quantized=False):
         o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); n = o.shape[0]

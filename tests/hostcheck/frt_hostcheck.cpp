@@ -214,4 +214,29 @@ void hc_trace(const frt_scene* s, int any, uint32_t n, const float* o, const flo
     }
 }
 
+// probe: the quad tree the default kernels walk. out = {quad nodes, stack need reported by the builder, stack need found by walking every
+// root-to-leaf path here, leaves reached, triangle slots covered by those leaves, children per node x 100}
+void hc_quad_stats(const frt_scene* s, uint32_t out[6]) {
+    const SceneBuilder& b = s->b;
+    out[0] = (uint32_t)b.quad_nodes.size(); out[1] = b.quad_stack_need; out[2] = out[3] = out[4] = out[5] = 0;
+    if (b.quad_nodes.empty()) return;
+    struct Item { uint32_t node, used; };
+    std::vector<Item> todo(1, Item{0u, 0u});
+    uint64_t kids = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back(); todo.pop_back();
+        const QuadNode& q = b.quad_nodes[it.node];
+        uint32_t refs[4]; int n = 0;
+        for (int i = 0; i < 4; ++i) { uint32_t r; memcpy(&r, &q.q[24 + i], 4); if (r != 0xFFFFFFFFu) refs[n++] = r; }
+        kids += (uint64_t)n;
+        const uint32_t used = it.used + (uint32_t)(n - 1);       // all children hit: n - 1 pushed while the nearest is entered
+        out[2] = std::max(out[2], used);
+        for (int i = 0; i < n; ++i) {
+            if (refs[i] & 0x80000000u) { out[3] += 1; out[4] += (refs[i] >> 24) & 0x7Fu; }
+            else todo.push_back(Item{refs[i], used});
+        }
+    }
+    out[5] = (uint32_t)(kids * 100u / b.quad_nodes.size());
+}
+
 } // extern "C"

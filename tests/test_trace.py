@@ -86,3 +86,37 @@ def test_hit_semantics(orc):
     # tmin / tmax are exclusive
     t2, _, _, _, _ = s.trace_closest(o[:1], d[:1], 0.001, 4.0, False)
     assert t2[0] == -1.0
+
+
+def test_quad_tree_covers_the_scene_and_fits_the_stack(frt, hostcheck):
+    """The quad tree the default kernels walk (frt_bvh.cpp: build_quad_nodes): every triangle slot under exactly one leaf, the same leaves as
+    the binary tree, and the deepest possible traversal stack — found by walking every root-to-leaf path with all children hit — within
+    the 32 entries of the kernels' LDS stacks, also for a tree at the builder's depth limit."""
+    fs = frt.scenes.create_cornell_box()
+    q = hostcheck.quad_stats(fs); b = fs.bvh_stats()
+    assert q["leaves"] == b["leaves"] and q["triangles"] == fs.get("bvh2_tri_index").size
+    assert q["stack_walked"] == q["stack_need"] <= 32 and q["nodes"] < b["pair_nodes"] * 0.6 and q["children_x100"] > 300
+    # a deep, lopsided tree: triangle sizes and positions in geometric progression make the SAH peel one triangle per level
+    n = 120
+    pos = np.zeros((3 * n, 4), np.float32); pos[:, 3] = 1.0
+    for i in range(n):
+        x = 2.0 ** i
+        pos[3 * i, :3] = (x, 0, 0); pos[3 * i + 1, :3] = (x * 1.05, 0.1 * x, 0); pos[3 * i + 2, :3] = (x, 0, 0.1 * x)
+    att = np.zeros((3 * n, 8), np.float32)
+    geo = frt.geometry.Geometry(pos, att, np.arange(3 * n, dtype=np.uint32))
+    sb = frt.SceneBuilder()
+    mesh = sb.add_mesh(geo)
+    mat = sb.add_material(frt.material_new([0.8, 0.8, 0.8, 1.0]))
+    sb.add_instance(mesh, mat, np.eye(4, dtype=np.float32).T)
+    deep = sb.build()
+    qd = hostcheck.quad_stats(deep); bd = deep.bvh_stats()
+    assert bd["depth"] >= 24, bd
+    assert qd["stack_walked"] == qd["stack_need"] <= 32 and qd["leaves"] == bd["leaves"] and qd["triangles"] == n, (qd, bd)
+    rng = np.random.default_rng(3)
+    pick = rng.integers(0, n, 2000)
+    tgt = (pos[3 * pick, :3] + pos[3 * pick + 1, :3] + pos[3 * pick + 2, :3]) / 3.0
+    o = (tgt + np.array([0.3, 1.0, 0.2], np.float32) * (2.0 ** pick)[:, None]).astype(np.float32)
+    d = (tgt - o).astype(np.float64); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t2, i2, _, _ = hostcheck.trace(deep, o, d.astype(np.float32), 0.0, 3e38, any_hit=False)
+    t4, i4, _, _ = hostcheck.trace(deep, o, d.astype(np.float32), 0.0, 3e38, any_hit=False, quantized=2)
+    assert np.array_equal(i2, i4) and np.array_equal(t2, t4) and (i2 != 0xFFFFFFFF).mean() > 0.2
