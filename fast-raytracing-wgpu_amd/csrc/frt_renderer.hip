@@ -523,10 +523,10 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     }
     HIP_TRY(hipMalloc((void**)&r->d_counters, C_COUNT * sizeof(unsigned long long)));
     {   // the bounce depths at which paths are cut, and the continuation queues
-        // Measured with the quad-tree kernels (tools/strip_time.py, tools/cut_sweep.sh): a 1080p frame 2.57 ms uncut, 2.09 cut at depth 3,
-        // 2.00 cut at 3 and 5, 1.96 at 3 and 4; half a frame 1.41 / 1.14 / 1.16; a quarter 0.76 / 0.66; an eighth 0.61 / 0.55. The second cut pays once the
-        // launch fills the chip several times over; a strip gets the first one only.
-        if ((size_t)r->W * (r->re - r->rb) < 1500000u) r->ncuts = 1;
+        // Measured with the quad-tree kernels (tools/cut_sweep.sh, tools/strip_cuts.py): a 1080p frame 2.57 ms uncut, 2.08 cut at depth 3,
+        // 1.97 at 3 and 5, 1.92 at 3 and 4; half a frame 1.41 uncut, 1.13 cut at 3, 1.09 at 3 and 4; a quarter 0.76 / 0.66 / 0.69; an
+        // eighth 0.61 / 0.57 / 0.61. The second cut pays once the launch fills the chip several times over; a thin strip gets the first only.
+        if ((size_t)r->W * (r->re - r->rb) < 800000u) r->ncuts = 1;
         if (const char* e = getenv("FRT_CUTS")) {   // experiment knob: comma-separated ascending depths, "0" = never cut
             r->ncuts = 0;
             uint32_t last = 0;

@@ -7,7 +7,7 @@ W, H = 1920, 1080
 scene = frt.scenes.create_cornell_box()
 cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(40)]
 for cuts, extra in (("0", frt.FLAG_OVERLAP_POST), ("3", frt.FLAG_OVERLAP_POST), ("default", frt.FLAG_OVERLAP_POST)):
-    if cuts == "default": os.environ.pop("FRT_CUTS", None)      # the renderer's own rule (uncut below 0.6 M pixels)
+    if cuts == "default": os.environ.pop("FRT_CUTS", None)      # the renderer's own rule
     else: os.environ["FRT_CUTS"] = cuts                         # read by frt_renderer_create
     for world in (1, 2, 4, 8):
         worst = 0
