@@ -3,7 +3,7 @@
 // Launch shape: one wave64 owns an 8x8 pixel tile (the reference's @workgroup_size(8,8), gbuffer.rs:302), four waves
 // per 256-thread workgroup = a 16x16 block. Each lane's BVH traversal stack is a column of an LDS array
 // (kStackDepth x 256 words = 32 KiB per workgroup; lane-consecutive addresses -> conflict-free ds_read/ds_write_b32).
-// Scene data (pair nodes 64 B, triangle slots 48 B) is read with 16-byte loads; per-pixel buffers are pixel-linear
+// Scene data (quad nodes 128 B, triangle slots 48 B: frt_trace.hpp) is read with 16-byte loads; per-pixel buffers are pixel-linear
 // float4 / 8-byte / 4-byte streams, so every wave-level access is a set of full 128-byte row segments.
 #include "frt_mono.hpp"
 #include "frt_kernels.hpp"
@@ -27,6 +27,7 @@ __device__ __forceinline__ bool tile_pixel(const FrameView& fv, uint32_t& px, ui
 // bottom eighth of the image reported in the stage's previous launch. A sweep, not a sort: orders that scatter the rows (or single
 // tiles) by cost were measured and lose more to the broken neighbourhood of consecutive workgroups (2.45 / 2.37 ms) than the shorter
 // tail gains (2.35 ms against 2.42 top to bottom). Scheduling only: which pixels a workgroup computes, never what it computes.
+// OPT-IN since the quad-tree kernels (FRT_TILE_ORDER=1): with them the sweep costs 1-2 % on one stream and on two (frt_renderer.hip).
 // State per traced stage (device memory, 6 words): [0] flip (1 = bottom tile row first), [1] ticket of finished workgroups,
 // [2..3] summed time of the top eighth, [4..5] of the bottom eighth. The LAST workgroup of a launch to finish (ticket) turns the two
 // sums into the next launch's direction and clears them: no extra kernel, nothing on the critical path.

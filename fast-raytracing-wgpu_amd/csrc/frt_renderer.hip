@@ -83,6 +83,7 @@ struct frt_renderer {
     uint32_t qcap = 0, qcap_max = 0;       // slots per queue; upper bound = every traced pixel parks
     uint32_t qslots[2][2] = {{0, 0}, {0, 0}};   // slots of each word buffer [stage][first | second buffer], derived from qcap (alloc_queues)
     uint64_t qbytes = 0;                   // device bytes of the word buffers
+    long cont_grid = -1;                   // FRT_CONT_GRID: slots the spatial continuation grids cover at least (-1: half the stage's pixels)
     bool qcap_fixed = false;               // capacity given by the caller: never grown
     uint32_t* d_qcount = nullptr;          // [stage 1|2][launch parity 0|1][kMaxCuts + 1] counters, then [stage] overflow counters
     uint32_t qparity[2] = {0, 0};
@@ -581,6 +582,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         if (const char* e = getenv("FRT_RESIDENT")) r->resident = atoi(e) != 0 && r->res_nodes > 0 && !(r->flags & FRT_FLAG_COMPACTION);
         if (const char* e = getenv("FRT_STREAM")) { r->stream_mode = atoi(e) != 0; if (atoi(e) > 1) r->shade_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: n > 1 = shade_min
         if (const char* e = getenv("FRT_WG_PARK")) r->wg_park = atoi(e) != 0;
+        if (const char* e = getenv("FRT_CONT_GRID")) r->cont_grid = std::max(0l, atol(e));
         if (const char* e = getenv("FRT_STREAM_SLICE")) r->stream_slice = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("FRT_REFILL")) { r->refill = atoi(e) != 0; if (atoi(e) > 1) r->refill_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: 0 off, 1 on, n > 1: refill when >= n lanes are free
         if ((r->refill || r->stream_mode) && !getenv("FRT_CUTS") && r->ncuts > 1) r->ncuts = 1;   // (those kernels replace the continuation launches of a single cut)
@@ -650,7 +652,7 @@ static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, Tr
     // 1.92 / 1.92 / 1.92; no effect on one stream, none for the T-trace launches on the ahead stream): while the grid is still being
     // dispatched the main stream keeps its turn at the dispatcher beside the next frame's T-trace pixel kernel (profiles/r2_schedule_notes.md).
     L.grid_min_slots = (stage == 2 && r->pipeline()) ? (uint32_t)std::min<uint64_t>(r->qcap_max, (uint64_t)r->W * (r->re - r->rb) / 2u) : 0u;
-    if (const char* e = getenv("FRT_CONT_GRID")) L.grid_min_slots = (uint32_t)atol(e);   // experiment knob
+    if (r->cont_grid >= 0) L.grid_min_slots = (uint32_t)r->cont_grid;   // (FRT_CONT_GRID: experiment knob, read at creation)
     L.overflow = r->d_qcount + 2 * 2 * (kMaxCuts + 1) + (stage - 1);
     L.tile_state = (with_tile_state && r->d_tiles) ? r->d_tiles + (size_t)(stage - 1) * kTileStateWords : nullptr;
     if (r->wavefront && cut) {
