@@ -259,6 +259,24 @@ def test_every_cut_configuration_is_bit_identical(gpu, orc, monkeypatch, cuts):
     assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
 
 
+@pytest.mark.parametrize("flags", [0, 8])
+def test_sweep_direction_is_scheduling_only(gpu, orc, monkeypatch, flags):
+    """FRT_TILE_ORDER=1 (opt-in since the quad-tree kernels): the traced pixel kernels sweep the tile rows from the expensive end of the image,
+    the direction fed back by the last workgroup of each launch. Which pixels a workgroup computes, never what: every buffer equals the oracle,
+    also while the direction flips between frames."""
+    frt = gpu
+    monkeypatch.setenv("FRT_TILE_ORDER", "1")
+    W, H = 192, 160
+    fs = frt.scenes.create_cornell_box()
+    os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    r = frt.Renderer(fs, W, H, flags=flags)
+    ro = os_.renderer(W, H, 8, True, 16)
+    for f in range(5):
+        cam = frt.CameraController().build_uniform(W / H, f, 2)
+        r.render(cam); ro.render(cam)
+        compare_all(r.read_buffer, ro.read, f, f"tile order, flags {flags}")
+
+
 def test_moving_camera_strips_equal_whole_image(gpu):
     """SURVEY §8f-2 on the GPU: three strip renderers with a motion halo + the two exchanges reproduce the single-renderer frames of a
     moving camera bit for bit, with and without the side-stream schedule; without the halo the reads are detected (halo_overflow)."""
