@@ -143,7 +143,12 @@ def main():
             bounds = balanced_boundaries(frt, scene, W, H, world, max_depth=MAX_DEPTH, device=local_rank)
         except Exception as e:      # equal strips are always valid; balancing is an optimisation
             print(f"[rank {rank}] work-balanced strips unavailable ({e}); using equal strips", file=sys.stderr)
-    plan = StripPlan(H, world, rank, bounds)
+    try:
+        plan = StripPlan(H, world, rank, bounds)
+    except ValueError as e:     # (cannot happen with balanced_boundaries' own guards; equal strips are always valid)
+        print(f"[rank {rank}] {e}; using equal strips", file=sys.stderr)
+        bounds = None
+        plan = StripPlan(H, world, rank, None)
     nbytes = frt.Renderer.arena_bytes(W, H)
     arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device=f"cuda:{local_rank}")
     off = (-arena.data_ptr()) % 256
