@@ -38,9 +38,12 @@ static const uint32_t kReuseRadius = 10;   // rows of temporal reservoirs a spat
 // order, so frame f+2 cannot start before f+1's latency-bound tail has drained — and is therefore not compiled in. Which physical set
 // holds which of the reference's two logical slots is tracked per frame (GSlots below), so any kSpecDepth works.
 static const int kSpecDepth = 1;             // frames whose G-buffer + T-trace may run ahead
-static const int kGSets = kSpecDepth + 1;
+static const int kGSets = 3;                 // physical G-buffer sets addressable; a renderer owns `gsets` of them (2, strips under the pipeline 3)
 enum { B_GPOS0 = 0, B_GNRM0 = B_GPOS0 + kGSets, B_GALB0 = B_GNRM0 + kGSets, B_GMOT0 = B_GALB0 + kGSets, B_CAND0 = B_GMOT0 + kGSets,
        B_RES0 = B_CAND0 + kGSets, B_RES1, B_RAW, B_DISP, B_ACC0, B_ACC1, B_COUNT };
+// Buffers outside the arena (frt_renderer_arena_bytes stays 228 B per pixel): the third G-buffer set. Only strip renderers under the pipeline
+// allocate them (frt_renderer::extras): with a third set the next frame's G-buffer + T-trace need not wait for this frame's T-merge.
+static bool is_extra(int b) { return b < B_RES0 && (b % kGSets) == 2; }
 static uint32_t bpp_of(int b) {
     if (b < B_GALB0) return 16u;        // gpos, gnormal
     if (b < B_GMOT0) return 4u;         // galbedo
@@ -55,7 +58,9 @@ struct GSlots { uint32_t g, gprev, aux; };   // physical sets: this frame's G-bu
 
 // Device counters (unsigned long long each): [0..7] committed rays per stage {closest, any}; [8] halo overflow;
 // [9..12] PENDING rays of a G-buffer + T-trace pair that ran ahead of its frame (committed by its T-merge, dropped with a discarded speculation)
-enum { C_STAGE = 0, C_HALO = 8, C_PENDING = 9, C_COUNT = 9 + 4 * kSpecDepth };   // one pending set of four per frame in flight ahead
+static const int kPending = 2;               // pending ray-count sets / T-trace events: consecutive speculated frames alternate (with three G-buffer sets
+                                             // T-trace(f+1) may start before T-merge(f) has committed the counts of T-trace(f))
+enum { C_STAGE = 0, C_HALO = 8, C_PENDING = 9, C_COUNT = 9 + 4 * kPending };   // a pending set of four per speculated frame in flight
 static const int kTileStateWords = 8;      // per traced stage (frt_kernels.hip: TileOrder uses 6)
 
 struct frt_renderer {
@@ -66,7 +71,7 @@ struct frt_renderer {
     hipStream_t edge = nullptr;            // FRT_FLAG_PIPELINE, strips: the spatial pixel launches of the halo-dependent edge rows (beside the interior launch)
     hipStream_t edge2 = nullptr;           // ... the second edge of a middle strip: its launch runs beside the first one's instead of behind it
     int spec_depth = kSpecDepth;           // frames speculated ahead (FRT_SPEC_DEPTH: experiment knob, 0 .. kSpecDepth)
-    hipEvent_t ev_spix = nullptr, ev_tt[kSpecDepth] = {}, ev_tail = nullptr, ev_tm = nullptr, ev_edge = nullptr, ev_edge2 = nullptr, ev_edge_ready = nullptr;
+    hipEvent_t ev_spix = nullptr, ev_tt[kPending] = {}, ev_tail = nullptr, ev_tm[2] = {nullptr, nullptr}, ev_edge = nullptr, ev_edge2 = nullptr, ev_edge_ready = nullptr;
     bool tail_pending = false;             // work enqueued on `ahead` that the main stream has not been ordered behind yet
     bool edge_in_flight = false, edge2_in_flight = false;
     uint32_t W = 0, H = 0, max_depth = 8, rb = 0, re = 0, flags = 0, motion_halo = 0;
@@ -119,13 +124,17 @@ struct frt_renderer {
     bool camera_static = false;
     frt_camera_uniform last_cam{}, cur_cam{};
     bool have_last_cam = false;
-    void* buf(int b) const { return arena + off[b]; }
+    uint8_t* extras = nullptr; size_t extras_bytes = 0;      // the buffers of is_extra(), when this renderer has them
+    uint32_t gsets = 2;                    // G-buffer sets in use
+    uint64_t serial = 0;                   // frames finished since creation (never reset: parity of the per-frame events)
+    void* buf(int b) const { return is_extra(b) ? extras + off[b] : arena + off[b]; }
     bool pipeline() const { return ahead != nullptr; }
 };
 
-static size_t arena_layout(uint32_t W, uint32_t H, size_t off[B_COUNT]) {
+static size_t arena_layout(uint32_t W, uint32_t H, size_t off[B_COUNT], bool extras = false) {
     size_t n = (size_t)W * H, cur = 0;
     for (int b = 0; b < B_COUNT; ++b) {
+        if (is_extra(b) != extras) continue;
         if (off) off[b] = cur;
         cur += (n * bpp_of(b) + 255u) & ~(size_t)255u;
     }
@@ -434,12 +443,13 @@ void frt_renderer_destroy(frt_renderer* r) {
     if (r->ahead) { (void)hipStreamSynchronize(r->ahead); (void)hipStreamDestroy(r->ahead); }
     if (r->edge) { (void)hipStreamSynchronize(r->edge); (void)hipStreamDestroy(r->edge); }
     if (r->edge2) { (void)hipStreamSynchronize(r->edge2); (void)hipStreamDestroy(r->edge2); }
-    for (hipEvent_t e : {r->ev_spix, r->ev_tail, r->ev_tm, r->ev_edge, r->ev_edge2, r->ev_edge_ready}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {r->ev_spix, r->ev_tail, r->ev_tm[0], r->ev_tm[1], r->ev_edge, r->ev_edge2, r->ev_edge_ready}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r->ev_tt) if (e) (void)hipEventDestroy(e);
     for (auto& t : r->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (hipEvent_t e : r->event_pool) (void)hipEventDestroy(e);
     for (void* p : r->scene_allocs) (void)hipFree(p);
     if (r->own_arena && r->arena) (void)hipFree(r->arena);
+    if (r->extras) (void)hipFree(r->extras);
     if (r->d_counters) (void)hipFree(r->d_counters);
     free_queues(r);
     if (r->d_qcount) (void)hipFree(r->d_qcount);
@@ -514,11 +524,17 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         HIP_TRY(hipStreamCreateWithPriority(&r->ahead, hipStreamNonBlocking, prio));
         HIP_TRY(hipStreamCreateWithPriority(&r->edge, hipStreamNonBlocking, prio));
         if (r->rb > 0 && r->re < r->H) HIP_TRY(hipStreamCreateWithPriority(&r->edge2, hipStreamNonBlocking, prio));   // a middle strip has two edges
-        for (hipEvent_t* e : {&r->ev_spix, &r->ev_tail, &r->ev_tm, &r->ev_edge, &r->ev_edge2, &r->ev_edge_ready}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&r->ev_spix, &r->ev_tail, &r->ev_tm[0], &r->ev_tm[1], &r->ev_edge, &r->ev_edge2, &r->ev_edge_ready}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
         for (hipEvent_t& e : r->ev_tt) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (const char* e = getenv("FRT_SPEC_DEPTH")) r->spec_depth = std::max(0, std::min(kSpecDepth, atoi(e)));   // experiment knob
     }
     r->arena_bytes = arena_layout(r->W, r->H, r->off);
+    // (experiment / test knobs: FRT_NO_EXTRAS = two G-buffer sets for strips too, FRT_FORCE_EXTRAS = three also for a whole-frame renderer)
+    if (r->pipeline() && (!(r->rb == 0 && r->re == r->H) || getenv("FRT_FORCE_EXTRAS")) && !getenv("FRT_NO_EXTRAS")) {
+        r->extras_bytes = arena_layout(r->W, r->H, r->off, true);
+        HIP_TRY(hipMalloc((void**)&r->extras, r->extras_bytes));
+        r->gsets = 3;
+    }
     if (o && o->device_arena) {
         if (o->arena_bytes < r->arena_bytes) return fail(FRT_ERR_INVALID_ARG, "device_arena smaller than frt_renderer_arena_bytes");
         if (((uintptr_t)o->device_arena & 255u) != 0) return fail(FRT_ERR_INVALID_ARG, "device_arena must be 256-byte aligned");
@@ -572,6 +588,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         }
     }
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));   // wgpu zero-initialises textures and buffers
+    if (r->extras) HIP_TRY(hipMemsetAsync(r->extras, 0, r->extras_bytes, r->stream));
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, C_COUNT * sizeof(unsigned long long), r->stream));
     int rc = upload_scene(r, s->b);
     if (rc) return rc;
@@ -718,7 +735,7 @@ static GSlots alloc_g(frt_renderer* r, uint32_t frame_count) {
     GSlots gs;
     if (!r->pipeline()) { gs.g = L; gs.gprev = L ^ 1u; gs.aux = 0u; r->logical_phys[0] = 0u; r->logical_phys[1] = 1u; return gs; }
     gs.g = r->logical_phys[L];      // two sets: the logical slot's own set (its frame's readers are done); more: a set neither slot points at
-    for (uint32_t p = 0; p < (uint32_t)kGSets; ++p)
+    for (uint32_t p = 0; p < r->gsets; ++p)
         if (p != r->logical_phys[0] && p != r->logical_phys[1]) { gs.g = p; break; }
     gs.gprev = r->logical_phys[L ^ 1u];
     gs.aux = gs.g;
@@ -745,7 +762,7 @@ static int open_frame(frt_renderer* r, const frt_camera_uniform* cam) {
             // sets back; the buffers it wrote are simply overwritten by the stages that follow
             int rc = fence_ahead(r);
             if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(r->d_counters + C_PENDING, 0, 4 * kSpecDepth * sizeof(unsigned long long), r->stream));
+            HIP_TRY(hipMemsetAsync(r->d_counters + C_PENDING, 0, 4 * kPending * sizeof(unsigned long long), r->stream));
             r->logical_phys[0] = sp.logical_before[0]; r->logical_phys[1] = sp.logical_before[1];
             r->stats.discarded_speculations += r->specs.size();
             r->specs.clear();
@@ -767,10 +784,15 @@ static int launch_speculation(frt_renderer* r, const frt_camera_uniform* cam) {
         sp.frame = (r->specs.empty() ? r->frame_count : r->specs.back().frame) + 1u;
         sp.logical_before[0] = r->logical_phys[0]; sp.logical_before[1] = r->logical_phys[1];
         sp.slots = alloc_g(r, sp.frame);
-        sp.idx = r->spec_next_idx; r->spec_next_idx = (r->spec_next_idx + 1) % kSpecDepth;
+        sp.idx = r->spec_next_idx; r->spec_next_idx = (r->spec_next_idx + 1) % kPending;
         FrameView fa;
         fill_frame_view(r, &sp.cam, sp.frame, sp.slots, fa);
-        HIP_TRY(hipStreamWaitEvent(r->ahead, r->ev_tm, 0));
+        // two sets: the launch overwrites the set this frame's T-merge reads as `prev` -> behind this T-merge; three sets: it overwrites the set of
+        // the frame before that, whose last reader is the PREVIOUS frame's T-merge (and post) -> a whole frame of slack for the ahead stream
+        // (only when this frame's own T-trace ran on the ahead stream too: a T-trace on the main stream shares the stage's queues and counters
+        // with the launch behind it and is ordered by this frame's T-merge event)
+        const bool relaxed = r->gsets >= 3 && r->from_speculation;
+        HIP_TRY(hipStreamWaitEvent(r->ahead, r->ev_tm[(r->serial + (relaxed ? 1u : 0u)) & 1u], 0));
         int rc = launch_g_and_trace(r, fa, r->ahead, true, true, sp.idx);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(r->ev_tt[sp.idx], r->ahead));
@@ -822,7 +844,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
             if (timed) { int rc = timer_begin(r, t, 4, r->stream); if (rc) return rc; }
             HIP_TRY(launch_merge(r->sv, fv, r->stream, r->from_speculation ? r->d_counters + C_PENDING + 4 * r->cur_spec_idx : nullptr, r->d_counters + C_STAGE));
             if (timed) { int rc = timer_end(r, t, r->stream); if (rc) return rc; }
-            if (r->pipeline()) HIP_TRY(hipEventRecord(r->ev_tm, r->stream));
+            if (r->pipeline()) HIP_TRY(hipEventRecord(r->ev_tm[r->serial & 1u], r->stream));
         }
         r->tm_done = true;
     }
@@ -864,7 +886,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
                 // the halo exchange (frt_renderer_stream(r, 2)); here it is ordered behind T-merge.
                 hipStream_t q = r->stream;
                 const bool any_edge = (ia > y0) || (y1 > ib);
-                if (r->edge && any_edge && ia < ib) { q = r->edge; HIP_TRY(hipStreamWaitEvent(r->edge, r->ev_tm, 0)); }
+                if (r->edge && any_edge && ia < ib) { q = r->edge; HIP_TRY(hipStreamWaitEvent(r->edge, r->ev_tm[r->serial & 1u], 0)); }
                 // A middle strip has two edges: the second launch goes to a stream of its own, ordered behind everything the edge stream holds
                 // so far (T-merge, the caller's exchange), so that the two run side by side (one after the other they cost a 1/8 strip 0.12 ms
                 // of its 0.52 ms frame: the spatial continuation waits for both).
@@ -913,6 +935,7 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
 int frt_renderer_end_frame(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "end_frame: null");
     r->frame_count += 1;   // renderer.rs:515
+    r->serial += 1;
     r->stats.frames += 1;
     if (r->frame_open) { r->last_cam = r->cur_cam; r->have_last_cam = true; r->before_last_slots = r->last_slots; r->last_slots = r->cur_slots; }
     r->frame_open = false;
@@ -965,6 +988,7 @@ int frt_renderer_clear(frt_renderer* r) {
     int rc = resolve_timing(r);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));
+    if (r->extras) HIP_TRY(hipMemsetAsync(r->extras, 0, r->extras_bytes, r->stream));
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, C_COUNT * sizeof(unsigned long long), r->stream));
     HIP_TRY(hipMemsetAsync(r->d_qcount, 0, kQcountWords * sizeof(uint32_t), r->stream));
     HIP_TRY(hipMemsetAsync(r->d_work, 0, kWorkWords * sizeof(uint32_t), r->stream));

@@ -355,12 +355,15 @@ def test_config2_4k_eight_strips_equal_whole(gpu):
     assert sum(s.stats()["rays_closest"] + s.stats()["rays_any"] for s in strips) == total
 
 
-def test_pipeline_speculation_is_adopted_for_a_static_camera_and_dropped_for_a_moving_one(gpu, orc):
+@pytest.mark.parametrize("three_sets", [False, True], ids=["two-sets", "three-sets"])
+def test_pipeline_speculation_is_adopted_for_a_static_camera_and_dropped_for_a_moving_one(gpu, orc, monkeypatch, three_sets):
     """FRT_FLAG_PIPELINE: G-buffer + T-trace of frame f+1 run ahead under a speculated camera. Static camera: adopted from the third
     frame on (one frame to see the camera, one to see that it did not move), every buffer and the ray counts identical to the oracle.
     Moving camera: never speculated (nothing to drop). A camera that stops / starts moving: wrong guesses are dropped, same pixels."""
     frt = gpu
     import _scenes
+    if three_sets:      # what strip renderers get: a third G-buffer set, the ahead stream ordered behind the PREVIOUS frame's T-merge; here on a
+        monkeypatch.setenv("FRT_FORCE_EXTRAS", "1")     # whole frame, so that frames enqueued back to back can be compared with the oracle
     W, H, N = 160, 96, 7
     fs = frt.scenes.create_cornell_box()
     os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
@@ -386,6 +389,58 @@ def test_pipeline_speculation_is_adopted_for_a_static_camera_and_dropped_for_a_m
     st, so = r.stats(), ro.stats()["total"]
     assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
     assert st["discarded_speculations"] in (1, 2) and st["speculated_frames"] >= 3, st     # (one guess per frame run ahead: FRT_SPEC_DEPTH)
+
+
+def test_three_gbuffer_sets_at_full_size_equal_two(gpu, monkeypatch):
+    """1920x1080, 16 frames enqueued back to back: a renderer with a third G-buffer set (ahead stream a whole frame ahead of the chain,
+    what strips run) against the default two sets: accumulation, both reservoir buffers, G-buffer and ray counts identical."""
+    frt = gpu
+    W, H, N = 1920, 1080, 16
+    fs = frt.scenes.create_cornell_box()
+    cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(N)]
+    a = frt.Renderer(fs, W, H, flags=frt.FLAG_PIPELINE)
+    monkeypatch.setenv("FRT_FORCE_EXTRAS", "1")
+    b = frt.Renderer(fs, W, H, flags=frt.FLAG_PIPELINE)
+    monkeypatch.delenv("FRT_FORCE_EXTRAS")
+    for c in cams:
+        a.render(c); b.render(c)
+    last = (N - 1) % 2
+    for buf, idx in ((7, last), (4, 0), (4, 1), (0, last), (1, last), (2, last), (5, 0)):
+        assert a.read_buffer(buf, idx).tobytes() == b.read_buffer(buf, idx).tobytes(), (buf, idx)
+    sa, sb = a.stats(), b.stats()
+    assert (sa["rays_closest"], sa["rays_any"]) == (sb["rays_closest"], sb["rays_any"]) and sb["speculated_frames"] == N - 2
+
+
+def test_strips_with_a_camera_that_starts_and_stops(gpu, orc):
+    """Strip renderers under the pipeline own a third G-buffer set, so the ahead stream is ordered behind the PREVIOUS frame's T-merge and
+    T-trace(f+1) may start before T-merge(f). Static -> moving -> static camera over three strips (middle strip: two edge launches), no
+    host synchronisation beyond the exchanges: adopted and dropped speculations, the hand-over between a T-trace on the main stream and the
+    next one on the ahead stream, pending ray counts of a dropped frame. Accumulation rows and the summed ray counts equal the oracle."""
+    frt = gpu
+    import _scenes
+    from frt.dist import StripPlan
+    W, H, K = 192, 144, 8
+    fs = frt.scenes.create_cornell_box()
+    os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
+    ro = os_.renderer(W, H, 8, True, 16)
+    plans = [StripPlan(H, 3, k, motion_halo=K) for k in range(3)]
+    strips = [frt.Renderer(fs, W, H, rows=(p.row_begin, p.row_end), flags=frt.FLAG_PIPELINE, motion_halo=K) for p in plans]
+    moving = _scenes.moving_camera_uniforms(frt, W / H, 2, 12)
+    seq = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(5)] + moving[5:8]
+    still = moving[7]
+    for f in range(8, 13):
+        c = frt.CameraUniform.from_buffer_copy(bytes(still)); c.frame_count = f; c.prev_view_proj[:] = list(still.view_proj); seq.append(c)
+    for f, cam in enumerate(seq):
+        ro.render(cam)
+        _strip_frame(frt, strips, plans, cam, f)
+        if f in (2, 4, 5, 7, 8, 10, 12):
+            want = ro.read(7, f % 2)
+            for s, p in zip(strips, plans):
+                assert s.read_buffer(7, f % 2)[p.row_begin:p.row_end].tobytes() == want[p.row_begin:p.row_end].tobytes(), (f, p.rank)
+    sts = [s.stats() for s in strips]
+    so = ro.stats()["total"]
+    assert sum(st["rays_closest"] for st in sts) == so["closest"] and sum(st["rays_any"] for st in sts) == so["any"]
+    assert all(st["speculated_frames"] >= 4 and st["discarded_speculations"] >= 1 and st["halo_overflow"] == 0 for st in sts), sts
 
 
 def test_queue_overflow_finishes_paths_in_place(gpu, orc):
