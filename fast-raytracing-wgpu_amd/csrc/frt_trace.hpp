@@ -203,7 +203,10 @@ FRT_HD void slab4(const char* n, uint32_t sx, uint32_t sy, uint32_t sz, f3 inv, 
         const float tn = fmaxn(fmaxn(xn[c], yn[c]), fmaxn(zn[c], tmin));
         const float tf = fminn(fminn(xf[c], yf[c]), fminn(zf[c], tlim));
         t[c] = tn;
-        h[c] = tn <= tf * 1.0000004f;
+        // No slack factor here (slab2 has one): the host pads every box by 1e-4 of the scene extent (frt_bvh.cpp), i.e. the entry / exit
+        // distances of a ray that hits a triangle inside are at least 1e-4 |1/d| apart from the hit on either side, four hundred times the
+        // rounding of the two fma and of the 1-ulp reciprocal (~2.4e-7 |1/d| for coordinates of the order of the extent).
+        h[c] = tn <= tf;
     }
 }
 template <bool ANY>
@@ -215,7 +218,7 @@ FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint
     const uint32_t sx = (f2u(d.x) >> 31) << 4, sy = (f2u(d.y) >> 31) << 4, sz = (f2u(d.z) >> 31) << 4;
     const uint32_t kDone = 0xFFFFFFFFu;
     const float kFar = 3.0e38f;
-    int sp = 0;
+    uint32_t* top = stk;      // next free stack entry (entries are `stride` words apart)
     uint32_t cur = 0u;   // quad node 0 is the root
     for (;;) {
         while (!(cur & 0x80000000u)) {
@@ -233,12 +236,12 @@ FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint
                        const uint32_t ra_ = s_ ? r[b] : r[a], rb_ = s_ ? r[a] : r[b]; k[a] = ka_; k[b] = kb_; r[a] = ra_; r[b] = rb_; }
             FRT_CE(0, 1) FRT_CE(2, 3) FRT_CE(0, 2) FRT_CE(1, 3) FRT_CE(1, 2)
 #undef FRT_CE
-            if (k[3] < kFar) { stk[(uint32_t)sp * stride] = r[3]; ++sp; }
-            if (k[2] < kFar) { stk[(uint32_t)sp * stride] = r[2]; ++sp; }
-            if (k[1] < kFar) { stk[(uint32_t)sp * stride] = r[1]; ++sp; }
+            if (k[3] < kFar) { *top = r[3]; top += stride; }
+            if (k[2] < kFar) { *top = r[2]; top += stride; }
+            if (k[1] < kFar) { *top = r[1]; top += stride; }
             if (k[0] < kFar) cur = r[0];
-            else if (sp == 0) cur = kDone;
-            else { --sp; cur = stk[(uint32_t)sp * stride]; }
+            else if (top == stk) cur = kDone;
+            else { top -= stride; cur = *top; }
         }
         if (cur == kDone) break;
         uint32_t first = cur & 0x00FFFFFFu, count = (cur >> 24) & 0x7Fu;
@@ -254,8 +257,8 @@ FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint
                 }
             }
         }
-        if (sp == 0) break;
-        --sp; cur = stk[(uint32_t)sp * stride];
+        if (top == stk) break;
+        top -= stride; cur = *top;
     }
     if (!ANY && hit.tri != 0xFFFFFFFFu) {
         bool front = best_det > 0.0f;
