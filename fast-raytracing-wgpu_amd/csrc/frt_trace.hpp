@@ -180,13 +180,14 @@ FRT_HD void trace(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint3
 // Near / far planes are picked by the sign of the ray direction: the near planes of a child are its lo planes for a positive direction
 // component and its hi planes for a negative one, so no min / max per axis is needed (4 instead of 10 instructions per child; fma is
 // monotonic, so these are the values min / max would select). `n` is the uniform base of the node array and sx, sy, sz the 32-bit byte
-// offsets of this lane's node plus 0 or 16 (direction component negative): uniform base + 32-bit lane offset keeps the seven loads of a
+// offsets of this lane's near planes (node offset | axis offset 0 / 32 / 64 | 16 where the direction component is negative; the far planes
+// are at that offset ^ 16): uniform base + 32-bit lane offset keeps the seven loads of a
 // step in the scalar-base addressing form (one offset register each instead of a 64-bit address).
 FRT_HD void slab4(const char* n, uint32_t sx, uint32_t sy, uint32_t sz, f3 inv, f3 oinv, float tmin, float tlim, float t[4], bool h[4]) {
     const char* base = n;
     const float4 nx = *reinterpret_cast<const float4*>(base + sx), fx = *reinterpret_cast<const float4*>(base + (sx ^ 16u));
-    const float4 ny = *reinterpret_cast<const float4*>(base + (32u + sy)), fy = *reinterpret_cast<const float4*>(base + (32u + (sy ^ 16u)));
-    const float4 nz = *reinterpret_cast<const float4*>(base + (64u + sz)), fz = *reinterpret_cast<const float4*>(base + (64u + (sz ^ 16u)));
+    const float4 ny = *reinterpret_cast<const float4*>(base + sy), fy = *reinterpret_cast<const float4*>(base + (sy ^ 16u));
+    const float4 nz = *reinterpret_cast<const float4*>(base + sz), fz = *reinterpret_cast<const float4*>(base + (sz ^ 16u));
     const frt_v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
     const frt_v2f ox = {oinv.x, oinv.x}, oy = {oinv.y, oinv.y}, oz = {oinv.z, oinv.z};
     const frt_v2f xn0 = __builtin_elementwise_fma(frt_v2f{nx.x, nx.y}, ix, ox), xn1 = __builtin_elementwise_fma(frt_v2f{nx.z, nx.w}, ix, ox);
@@ -215,7 +216,7 @@ FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint
     float best_det = 0.0f;
     f3 inv = mk3(prune_rcp(d.x), prune_rcp(d.y), prune_rcp(d.z));
     f3 oinv = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
-    const uint32_t sx = (f2u(d.x) >> 31) << 4, sy = (f2u(d.y) >> 31) << 4, sz = (f2u(d.z) >> 31) << 4;
+    const uint32_t sx = (f2u(d.x) >> 31) << 4, sy = 32u | ((f2u(d.y) >> 31) << 4), sz = 64u | ((f2u(d.z) >> 31) << 4);
     const uint32_t kDone = 0xFFFFFFFFu;
     const float kFar = 3.0e38f;
     uint32_t* top = stk;      // next free stack entry (entries are `stride` words apart)
@@ -226,7 +227,7 @@ FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint
             const char* nb = reinterpret_cast<const char*>(sc.nodes4);
             const float4 rf = *reinterpret_cast<const float4*>(nb + (noff + 96u));
             float t[4]; bool h[4];
-            slab4(nb, noff + sx, noff + sy, noff + sz, inv, oinv, tmin, ANY ? tmax : hit.t, t, h);
+            slab4(nb, noff | sx, noff | sy, noff | sz, inv, oinv, tmin, ANY ? tmax : hit.t, t, h);
             uint32_t r[4] = {f2u(rf.x), f2u(rf.y), f2u(rf.z), f2u(rf.w)};
             // (an empty slot holds a far-away degenerate box: it never passes the slab test, no reference check needed)
             float k[4];
@@ -245,18 +246,23 @@ FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint
         }
         if (cur == kDone) break;
         uint32_t first = cur & 0x00FFFFFFu, count = (cur >> 24) & 0x7Fu;
-        for (uint32_t kk = 0; kk < count; ++kk) {
-            const float4* tp = sc.tris + (size_t)(first + kk) * 3u;
+        // leaves hold one or two triangles (frt_bvh.cpp; up to four under FRT_BVH_LEAF): the first two are tested in line, without a loop
+        auto test = [&](uint32_t slot) -> bool {
+            const float4* tp = sc.tris + (size_t)slot * 3u;
             float4 a = tp[0], b = tp[1], c = tp[2];
             float t, u, v, det;
             if (intersect_tri(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, d, tmin, tmax, t, u, v, det)) {
                 uint32_t id = f2u(a.w);
-                if (ANY) { hit.tri = id; hit.t = t; return; }
+                if (ANY) { hit.tri = id; hit.t = t; return true; }
                 if (t < hit.t || (t == hit.t && id < hit.tri)) {
                     hit.t = t; hit.u = u; hit.v = v; hit.tri = id; hit.inst = f2u(b.w); best_det = det;
                 }
             }
-        }
+            return false;
+        };
+        if (test(first)) return;
+        if (count > 1u && test(first + 1u)) return;
+        for (uint32_t kk = 2u; kk < count; ++kk) if (test(first + kk)) return;
         if (top == stk) break;
         top -= stride; cur = *top;
     }
