@@ -36,11 +36,11 @@ PMC_JSON = os.path.join(ROOT, "profiles", "r2_pmc.json")     # written by tools/
 
 
 def source_hash():
-    """sha256 over the kernel sources the PMC passes were measured on (csrc/*.hip, *.hpp): a profile of other code is stale."""
+    """sha256 over the kernel sources the PMC passes were measured on (csrc/*.hip, *.hpp, the Makefile): a profile of other code is stale."""
     import glob, hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "fast-raytracing-wgpu_amd", "csrc", "*.h*"))):
-        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    for f in sorted(glob.glob(os.path.join(ROOT, "fast-raytracing-wgpu_amd", "csrc", "*.h*"))) + [os.path.join(ROOT, "fast-raytracing-wgpu_amd", "Makefile")]:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())       # (the Makefile: compiler flags change the kernels too)
     return h.hexdigest()[:16]
 
 
