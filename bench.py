@@ -10,8 +10,11 @@ Metric (BASELINE.json): Mrays/s = (closest-hit + any-hit rays issued, counted on
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 N > 1: one process per GPU, the frame is cut into N horizontal strips, two halo exchanges per frame over RCCL (frt.dist);
-total work is fixed ("strong" scaling). Rank 0 prints ONE JSON line.
-Extra objects: "roofline" (dominant kernel, HBM bound, algorithmic bytes per SURVEY.md §8d / DESIGN.md §6) and, at N = 1,
+total work is fixed ("strong" scaling). Rank 0 prints ONE JSON line. Either launch form works: with RANK / WORLD_SIZE in the
+environment this process IS a rank; without them `--gpus N` starts its own N rank processes (fresh children, before this
+process has touched the GPU), relays rank 0's line and exits non-zero if any rank fails.
+`--native`: ONE process drives the N GPUs through the C ABI's frt_multi_renderer (include/frt.h), no torch.distributed.
+Extra objects: "roofline" (what binds the frame, from the committed counters) and, at N = 1,
 "cpu_baseline" (the scalar C++ oracle over the same BVH on the host cores — a reported baseline, never the target).
 """
 import argparse
@@ -26,13 +29,16 @@ sys.path.insert(0, os.path.join(ROOT, "fast-raytracing-wgpu_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H, MAX_DEPTH = 1920, 1080, 8
+W4K, H4K = 3840, 2160          # BASELINE.json configs[2]
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+L2_PEAK_GBS = 34500.0          # same guide, §L2: ~34.5 TB/s aggregate over the 8 XCDs
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 256 CUs x 4 SIMD-32 x 2.4 GHz: 78.6 T lane-operations/s (= 157.3 TFLOP/s of fma)
 STAGES = ("gbuffer", "temporal", "spatial", "post")
 # Compulsory per-pixel stream bytes of each kernel in this design: G-buffer write 44; temporal = T-trace (read 36, write the
 # 16-byte candidate) + T-merge (read candidate 16, G-buffer 36 + previous 36 + motion 8, previous spatial reservoir 32, write 32) = 212;
 # spatial read 36+32, write 32+8; post read 68, write 20.
 B_PX = {"gbuffer": 44, "temporal": 212, "spatial": 108, "post": 88}
-PMC_JSON = os.path.join(ROOT, "profiles", "r2_pmc.json")     # written by tools/pmc_to_json.py on the GPU box, committed
+PMC_JSON = os.path.join(ROOT, "profiles", "r3_pmc.json")     # written by tools/pmc_to_json.py on the GPU box, committed
 
 
 def source_hash():
@@ -97,7 +103,7 @@ def cpu_baseline(scene, cams, n_frames):
             "ms_per_frame": secs / n_frames * 1e3}, per_stage
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -106,18 +112,176 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1. nccl (= RCCL over xGMI) is the real thing; gloo stages the halo rows through the "
                          "host and lets several ranks share ONE GPU (set FRT_BENCH_ONE_GPU=1) to rehearse the N > 1 code path on a 1-GPU box")
-    a = ap.parse_args()
+    ap.add_argument("--native", action="store_true",
+                    help="N > 1 in ONE process through frt_multi_renderer (C ABI): strips on N devices, peer copies for the halos; "
+                         "FRT_BENCH_ONE_GPU=1 maps every logical device to ordinal 0")
+    ap.add_argument("--no-4k", action="store_true", help="skip the extra configs[2] (3840x2160) measurement")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous plumbing only: every rank joins the process group and reports itself; nothing is rendered, no GPU is touched (CPU test)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------ self-launch
+def self_launch(a, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU), relay rank 0's JSON line.
+    Runs BEFORE torch / frt are imported: this process never initialises the GPU (and never execs), the children start clean."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(a.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FRT_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr))
+    deadline = time.time() + float(os.environ.get("FRT_BENCH_TIMEOUT", "1500"))
+    failed = None
+    out0 = b""
+    import threading
+
+    def drain():
+        nonlocal out0
+        out0 = procs[0].stdout.read()
+    t = threading.Thread(target=drain, daemon=True)
+    t.start()
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            failed = "timeout"
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:            # the exact processes started above, nothing else
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    t.join(timeout=10)
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    if failed:
+        raise SystemExit(f"bench.py: {failed} (launched {a.gpus} ranks on 127.0.0.1:{port})")
+    return 0
+
+
+def rank_env():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+
+
+def dry_run(a):
+    """Rendezvous only (gloo, CPU): proves that the launcher started `world` ranks that can talk. One JSON line from rank 0."""
+    world, rank, local_rank = rank_env()
+    info = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
+    ranks = [info]
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, info)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "config": {"ranks": ranks, "backend": "gloo" if world > 1 else None,
+                                                                        "self_launched": os.environ.get("FRT_BENCH_SELF_LAUNCHED") == "1"}}), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------------------ measurement
+def timed_loop(frame, first, warmup, steps, sync, barrier, stats):
+    """`warmup` untimed frames, then exactly `steps` frames between barrier + synchronize on both sides. Returns (seconds, stats before, stats after)."""
+    for f in range(first, first + warmup):
+        frame(f)
+    sync()
+    s0 = stats()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for f in range(first + warmup, first + warmup + steps):
+        frame(f)
+    sync()
+    barrier()
+    sync()
+    return time.perf_counter() - t0, s0, stats()
+
+
+def rays_of(s0, s1):
+    return (s1["rays_closest"] + s1["rays_any"]) - (s0["rays_closest"] + s0["rays_any"])
+
+
+def roofline_block(world, frame_ms, stages, px_rows):
+    """What binds the frame, read from the committed counters (profiles/r3_pmc.json, withheld when measured on other kernel sources).
+    The scene is L2-resident, so neither roofline the task names (hbm, mfma) binds: the frame is bound by the LATENCY of dependent vector
+    instructions between L1 round trips at 4 waves per SIMD. `bound`/`achieved`/`peak`/`frac` therefore describe the vector ALU
+    (wave-instructions x 64 lanes per second against 256 CUs x 4 SIMD-32 x 2.4 GHz); `useful_lane_frac` = that x the lane utilisation is the
+    number to drive up. The §8(d) algorithmic-bytes figure is carried as `logical_*`, the PMC HBM bytes as `traffic` / `hbm_actual`."""
+    algo_frame = sum(v["algorithmic_bytes"] for v in stages.values())
+    logical = algo_frame / (frame_ms * 1e-3) / 1e9
+    pmc = load_pmc() if world == 1 else None
+    roof = {"bound": "valu-issue latency (vector ALU; not hbm, not mfma: the scene lives in L2)",
+            "kernel": "frame = gbuffer_kernel + pixel_kernel<1> + continue_kernel<1> + merge_kernel + pixel_kernel<2> + continue_kernel<2> + post_kernel, co-scheduled on two streams",
+            "achieved": None, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s (VALU wave-instructions x 64 lanes)", "frac": None, "traffic": None,
+            "avg_launch_ms": frame_ms,
+            "logical_GBs": logical, "logical_frac": logical / HBM_PEAK_GBS, "logical_frac_of_l2_peak": logical / L2_PEAK_GBS,
+            "algorithmic_bytes_per_launch": algo_frame, "stages": stages,
+            "note": "logical_* = SURVEY 8(d) algorithmic bytes (BVH2 nodes and triangles per ray as the oracle counts them + compulsory per-pixel streams) over the frame time, "
+                    "against the HBM peak (logical_frac) and the aggregate L2 peak; served by the CUs' L1 / the XCDs' L2, so it is NOT an HBM roofline"}
+    if pmc:
+        lane_ops = pmc["valu_insts_per_frame"] * 64.0
+        roof["achieved"] = lane_ops / (frame_ms * 1e-3) / 1e12
+        roof["frac"] = roof["achieved"] / VALU_PEAK_TLANEOPS
+        roof["traffic"] = pmc["hbm_bytes_per_frame"]
+        hbm = pmc["hbm_bytes_per_frame"] / (frame_ms * 1e-3) / 1e9
+        roof["hbm_actual"] = {"GBs": hbm, "frac": hbm / HBM_PEAK_GBS, "traffic_over_algorithmic": pmc["hbm_bytes_per_frame"] / algo_frame}
+        simd_cycles = frame_ms * 1e-3 * pmc["shader_clock_ghz"] * 1e9 * pmc["simds"]
+        issue = pmc["valu_insts_per_frame"] * pmc["cycles_per_valu_inst"] / simd_cycles
+        lu = pmc.get("lane_utilisation") or {}
+        # lane utilisation of the frame: VALU thread-cycles over 64 x VALU instruction-cycles, summed over the frame's launches
+        num = sum(k.get("SQ_THREAD_CYCLES_VALU", 0.0) * k["launches_per_frame"] for k in pmc["kernels"].values())
+        den = sum(64.0 * k.get("SQ_ACTIVE_INST_VALU", 0.0) * k["launches_per_frame"] for k in pmc["kernels"].values())
+        frame_lu = num / den if den else None
+        roof["valu_issue"] = {"wave_insts_per_frame": pmc["valu_insts_per_frame"], "cycles_per_wave_inst": pmc["cycles_per_valu_inst"],
+                              "shader_clock_ghz": pmc["shader_clock_ghz"], "frac_at_measured_clock": issue,
+                              "lane_utilisation": lu, "lane_utilisation_frame": frame_lu}
+        roof["useful_lane_frac"] = issue * frame_lu if frame_lu else None
+        if pmc.get("l1"):
+            roof["l1"] = pmc["l1"]          # TCP hit rates / TA busy of the traced kernels (tools/pmc_ta.sh)
+        roof["pmc_source"] = {"file": os.path.relpath(PMC_JSON, ROOT), "source_hash": pmc["source_hash"], "git_head": pmc.get("git_head")}
+    elif world == 1:
+        roof["pmc_source"] = f"{os.path.relpath(PMC_JSON, ROOT)} is absent or was measured on other kernel sources: achieved / frac / traffic / hbm_actual / valu_issue withheld"
+    else:
+        roof["pmc_source"] = "counters are collected at N = 1 only"
+    return roof
+
+
+def main():
+    a = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and env_world is None and not a.native:
+        return self_launch(a, sys.argv[1:])          # nothing GPU-related has been imported or called yet
+    if a.dry_run:
+        return dry_run(a)
+    if a.native:
+        return main_native(a)
 
     import torch
     import frt
+    world, rank, local_rank = rank_env()
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     if frt.lib().frt_device_count() < 1:
         raise SystemExit("bench.py: no HIP device — the product has no CPU path")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch N > 1 with torch.distributed.run")
-    if os.environ.get("FRT_BENCH_ONE_GPU") == "1":
+    one_gpu = os.environ.get("FRT_BENCH_ONE_GPU") == "1"
+    if one_gpu:
         local_rank = 0                        # rehearsal: every rank renders on cuda:0 (gloo only)
     torch.cuda.set_device(local_rank)
     dist = None
@@ -133,8 +297,10 @@ def main():
     scene = frt.scenes.create_cornell_box()
     nl = scene.num_lights
     total = a.warmup + a.steps
+    n_inst = min(16, a.steps)
+    nq = max(8, a.steps // 2)
     cam_ctl = frt.CameraController()
-    cams = [cam_ctl.build_uniform(W / H, f, nl) for f in range(max(total + 17 + max(8, a.steps), a.cpu_frames + 1))]
+    cams = [cam_ctl.build_uniform(W / H, f, nl) for f in range(max(total + n_inst + nq + 1, a.cpu_frames + 1))]
 
     # strips of equal WORK (probe render, identical on every rank), not equal height
     bounds = None
@@ -149,41 +315,31 @@ def main():
         print(f"[rank {rank}] {e}; using equal strips", file=sys.stderr)
         bounds = None
         plan = StripPlan(H, world, rank, None)
-    nbytes = frt.Renderer.arena_bytes(W, H)
-    arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device=f"cuda:{local_rank}")
-    off = (-arena.data_ptr()) % 256
     stream = torch.cuda.current_stream()
-    # Same instrumentation at every N: the two-stream schedule, NO per-stage events inside the timed region (two event records per stage and
-    # frame cost a thin strip 0.04 of its 0.43 ms); the per-stage times of the JSON line come from a short instrumented pass afterwards.
-    r = frt.Renderer(scene, W, H, max_depth=MAX_DEPTH, device=local_rank, stream=stream.cuda_stream,
-                     rows=(plan.row_begin, plan.row_end) if world > 1 else None,
-                     arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_PIPELINE)
-    rows = ArenaRows(r, arena, staging_device=None if a.backend == "nccl" else "cpu")
 
-    def frame(f):
+    def make(width, height, pl):
+        nbytes = frt.Renderer.arena_bytes(width, height)
+        arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        off = (-arena.data_ptr()) % 256
+        # Same instrumentation at every N: the two-stream schedule, NO per-stage events inside the timed region (two event records per stage and
+        # frame cost a thin strip 0.04 of its 0.43 ms); the per-stage times of the JSON line come from a short instrumented pass afterwards.
+        r = frt.Renderer(scene, width, height, max_depth=MAX_DEPTH, device=local_rank, stream=stream.cuda_stream,
+                         rows=(pl.row_begin, pl.row_end) if world > 1 else None,
+                         arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_PIPELINE)
+        return r, ArenaRows(r, arena, staging_device=None if a.backend == "nccl" else "cpu")
+
+    r, rows = make(W, H, plan)
+
+    def frame_fn(rr, rws, pl, cam_list):
         if world == 1:
-            r.render(cams[f])
-        else:
-            render_strip_frame(r, rows, plan, cams[f], f, frt)
+            return lambda f: rr.render(cam_list[f])
+        return lambda f: render_strip_frame(rr, rws, pl, cam_list[f], f, frt)
 
-    for f in range(a.warmup):
-        frame(f)
-    torch.cuda.synchronize()
-    s0 = r.stats()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for f in range(a.warmup, total):
-        frame(f)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    s1 = r.stats()
+    frame = frame_fn(r, rows, plan, cams)
+    sync = torch.cuda.synchronize
+    barrier = dist.barrier if dist else (lambda: None)
+    elapsed, s0, s1 = timed_loop(frame, 0, a.warmup, a.steps, sync, barrier, r.stats)
     # instrumented pass (outside the timed region): the same frame loop with the per-stage HIP events on
-    n_inst = min(16, a.steps)
     r.set_timing(True)
     si0 = r.stats()
     for f in range(total, total + n_inst):
@@ -193,7 +349,7 @@ def main():
     r.set_timing(False)
     first_extra = total + n_inst
 
-    rays = (s1["rays_closest"] + s1["rays_any"]) - (s0["rays_closest"] + s0["rays_any"])
+    rays = rays_of(s0, s1)
     exposed_ms = None
     if dist:
         # What the halo transfers cost per frame: the same frame loop with the transfers switched off (the pixels of those frames are
@@ -202,7 +358,6 @@ def main():
             def transfers(self, frame, when="mid"):
                 return []
         quiet = _NoTransfers(H, world, rank, bounds)
-        nq = max(8, a.steps // 2)
         dist.barrier(); torch.cuda.synchronize()
         tq = time.perf_counter()
         for f in range(first_extra, first_extra + nq):
@@ -212,13 +367,44 @@ def main():
         tqm = torch.tensor([quiet_ms], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tqm, op=dist.ReduceOp.MAX)
         exposed_ms = elapsed / a.steps * 1e3 - float(tqm.item())
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+
+    def reduce_time_rays(el, n_rays):
+        if not dist:
+            return el, n_rays
+        t = torch.tensor([el], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        n = torch.tensor([rays], dtype=torch.int64, device=comm_dev)
+        n = torch.tensor([n_rays], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
-        rays = int(n.item())
+        return float(t.item()), int(n.item())
+
+    elapsed, rays = reduce_time_rays(elapsed, rays)
+
+    # who ran: every rank reports its device and rows; a sum over the process group proves that `world` ranks took part in a collective
+    me = {"rank": rank, "device": local_rank, "device_name": torch.cuda.get_device_name(local_rank), "rows": [plan.row_begin, plan.row_end],
+          "rays_per_frame": rays_of(s0, s1) / a.steps, "pid": os.getpid()}
+    ranks, allreduce_ranks = [me], 1
+    if dist:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        one = torch.ones(1, dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(one)
+        allreduce_ranks = int(one.item())
+
+    # configs[2]: the same scene at 3840x2160, the workload BASELINE.json tiles over 8 GPUs (extra key; the headline stays configs[1])
+    extra4k = None
+    if not a.no_4k:
+        del r, rows, frame
+        torch.cuda.empty_cache()
+        plan4 = StripPlan(H4K, world, rank, [b * 2 for b in bounds] if bounds else None)
+        k4, w4 = max(4, min(16, a.steps)), 4
+        cams4 = [frt.CameraController().build_uniform(W4K / H4K, f, nl) for f in range(k4 + w4)]
+        r4, rows4 = make(W4K, H4K, plan4)
+        el4, q0, q1 = timed_loop(frame_fn(r4, rows4, plan4, cams4), 0, w4, k4, sync, barrier, r4.stats)
+        el4, rays4 = reduce_time_rays(el4, rays_of(q0, q1))
+        extra4k = {"workload": "Cornell Box 3840x2160, MAX_DEPTH 8 (BASELINE.json configs[2])", "value": rays4 / el4 / 1e6, "unit": "Mrays/s",
+                   "ms_per_step": el4 / k4 * 1e3, "steps": k4, "warmup": w4, "rays_per_frame": rays4 / k4,
+                   "rows": [plan4.row_begin, plan4.row_end] if world == 1 else plan4.boundaries}
+        del r4, rows4
 
     if rank == 0:
         K = a.steps
@@ -237,33 +423,10 @@ def main():
         for i, name in enumerate(STAGES):
             npr, tpr = (per_stage[name]["nodes_per_ray"], per_stage[name]["tris_per_ray"]) if per_stage and name in per_stage else defaults[name]
             algo = stage_rays[i] * (32.0 * npr + 48.0 * tpr) + px * B_PX[name]
-            stages[name] = {"event_ms": ms[i], "rays": stage_rays[i], "bytes_per_ray": 32.0 * npr + 48.0 * tpr, "algorithmic_bytes": algo,
-                            "logical_GBs_over_event_ms": algo / (ms[i] * 1e-3) / 1e9 if ms[i] > 0 else 0.0}
+            stages[name] = {"event_ms": ms[i], "rays": stage_rays[i], "bytes_per_ray": 32.0 * npr + 48.0 * tpr, "algorithmic_bytes": algo}
         stages["temporal"]["merge_event_ms"] = ms_merge
-        # The stages of a frame are co-scheduled on two streams (G-buffer + T-trace of frame f+1 and post(f) run beside spatial(f)), so a
-        # stage's event time includes the time it shares the chip: the roofline is quoted for the frame's kernel set as a whole, over
-        # the wall time of the timed region; the per-stage event times are listed beside it. (Round 1 quoted the spatial stage alone:
-        # 7.17 GB / 1.33 ms = 0.68; its whole-frame figure was 11.9 GB / 2.356 ms = 0.63.)
         frame_ms = elapsed / K * 1e3
-        algo_frame = sum(v["algorithmic_bytes"] for v in stages.values())
-        achieved = algo_frame / (frame_ms * 1e-3) / 1e9
-        pmc = load_pmc() if world == 1 else None
-        roof = {"bound": "hbm", "kernel": "frame = gbuffer_kernel + pixel_kernel<1> + continue_kernel<1> + merge_kernel + pixel_kernel<2> + continue_kernel<2> + post_kernel, co-scheduled on two streams",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc["hbm_bytes_per_frame"] if pmc else None, "avg_launch_ms": frame_ms, "algorithmic_bytes_per_launch": algo_frame,
-                "stages": stages,
-                "note": "logical BVH + stream bytes per SURVEY 8(d); the scene (91 KB) is L2-resident, so HBM carries only the per-pixel streams (traffic << algorithmic bytes) and the binding resource is the vector ALU / L2 latency: see hbm_actual and valu_issue"}
-        if pmc:
-            # HBM-actual: the PMC bytes over this run's frame time. VALU issue: wave-instructions of one frame (deterministic) x the calibrated
-            # SIMD cycles per wave-instruction (tools/valu_calib.hip) over the SIMD-cycles the frame lasted.
-            roof["hbm_actual"] = {"GBs": pmc["hbm_bytes_per_frame"] / (frame_ms * 1e-3) / 1e9, "frac": pmc["hbm_bytes_per_frame"] / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            simd_cycles = frame_ms * 1e-3 * pmc["shader_clock_ghz"] * 1e9 * pmc["simds"]
-            roof["valu_issue"] = {"wave_insts_per_frame": pmc["valu_insts_per_frame"], "cycles_per_wave_inst": pmc["cycles_per_valu_inst"],
-                                  "frac": pmc["valu_insts_per_frame"] * pmc["cycles_per_valu_inst"] / simd_cycles,
-                                  "lane_utilisation": pmc.get("lane_utilisation")}
-            roof["pmc_source"] = {"file": "profiles/r2_pmc.json", "source_hash": pmc["source_hash"], "git_head": pmc.get("git_head")}
-        elif world == 1:
-            roof["pmc_source"] = "profiles/r2_pmc.json is absent or was measured on other kernel sources: traffic / hbm_actual / valu_issue withheld"
+        roof = roofline_block(world, frame_ms, stages, px)
         par = "1 GPU, two-stream schedule"
         if world > 1:
             par = (f"{world} work-balanced image strips {bounds}; per frame 2 halo exchanges per neighbour ({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'}): "
@@ -275,12 +438,17 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell Box 1920x1080, MAX_DEPTH 8, 1 candidate path/pixel/frame, 4-stage ReSTIR-PT frame (BASELINE.json configs[1])",
                        "rays_per_frame": rays / a.steps, "parallelism": par,
+                       "backend": (dist.get_backend() if dist else None), "process_group_world_size": (dist.get_world_size() if dist else 1),
+                       "allreduce_of_ones": allreduce_ranks, "ranks": ranks, "one_gpu_rehearsal": one_gpu,
+                       "self_launched": os.environ.get("FRT_BENCH_SELF_LAUNCHED") == "1",
                        "speculated_frames": s1["speculated_frames"] - s0["speculated_frames"], "queue_overflow": s1["queue_overflow"],
                        "exchange_exposed_ms": exposed_ms},
             "roofline": roof,
             "stage_ms": dict(zip(STAGES, ms)),
             "stage_ms_note": f"per-stage HIP event times of a separate instrumented pass of {n_inst} frames after the timed region (the timed region records no events)",
         }
+        if extra4k:
+            out["config2_4k"] = extra4k
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
@@ -289,5 +457,38 @@ def main():
         dist.destroy_process_group()
 
 
+def main_native(a):
+    """One process, N devices, through the C ABI's multi-device renderer (include/frt.h: frt_multi_renderer_*): what a Rust host calls."""
+    import frt
+    if frt.lib().frt_device_count() < 1:
+        raise SystemExit("bench.py: no HIP device — the product has no CPU path")
+    one_gpu = os.environ.get("FRT_BENCH_ONE_GPU") == "1"
+    devices = [0] * a.gpus if one_gpu else list(range(a.gpus))
+    scene = frt.scenes.create_cornell_box()
+    nl = scene.num_lights
+
+    def run(width, height, warmup, steps):
+        mr = frt.MultiRenderer(scene, width, height, devices, max_depth=MAX_DEPTH)
+        cams = [frt.CameraController().build_uniform(width / height, f, nl) for f in range(warmup + steps)]
+        el, s0, s1 = timed_loop(lambda f: mr.render(cams[f]), 0, warmup, steps, mr.sync, lambda: None, mr.stats)
+        return mr, el, rays_of(s0, s1)
+
+    mr, elapsed, rays = run(W, H, a.warmup, a.steps)
+    out = {"metric": "Mrays/sec, 1920x1080 8-bounce Cornell Box", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
+           "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "Cornell Box 1920x1080, MAX_DEPTH 8, 1 candidate path/pixel/frame, 4-stage ReSTIR-PT frame (BASELINE.json configs[1])",
+                      "rays_per_frame": rays / a.steps,
+                      "parallelism": f"frt_multi_renderer: ONE process, {a.gpus} strip renderers on devices {devices}, halo rows by hipMemcpyPeerAsync, boundaries {mr.boundaries()}",
+                      "one_gpu_rehearsal": one_gpu, "native": True}}
+    del mr
+    if not a.no_4k:
+        k4 = max(4, min(16, a.steps))
+        mr4, el4, rays4 = run(W4K, H4K, 4, k4)
+        out["config2_4k"] = {"workload": "Cornell Box 3840x2160, MAX_DEPTH 8 (BASELINE.json configs[2])", "value": rays4 / el4 / 1e6, "unit": "Mrays/s",
+                             "ms_per_step": el4 / k4 * 1e3, "steps": k4, "warmup": 4, "rays_per_frame": rays4 / k4, "rows": mr4.boundaries()}
+    print(json.dumps(out), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -21,6 +21,18 @@ namespace frt { int set_error(int code, const std::string& msg) { return fail(co
         if (e_ != hipSuccess) return fail(FRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Every entry point that touches the device makes the renderer's device current and gives the caller's back on return (a host that
+// drives several devices from one thread — frt_multi_renderer does — must not find its current device changed by a call).
+struct DeviceGuard {
+    int prev = -1; bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define FRT_DEVICE(r) DeviceGuard guard_((r)->device); if (!guard_.ok) return fail(FRT_ERR_HIP, "hipSetDevice failed")
+
 static_assert(sizeof(frt_vertex_attr) == 32 && sizeof(frt_material) == 64 && sizeof(frt_light) == 64, "ABI struct sizes");
 static_assert(sizeof(frt_camera_uniform) == 288 && sizeof(frt_reservoir) == 32 && sizeof(frt_bvh2_node) == 32, "ABI struct sizes");
 static_assert(sizeof(CameraView) == 288 && sizeof(ReservoirView) == 32 && sizeof(InstanceView) == 64 && sizeof(InstanceDev) == 64, "view sizes");
@@ -109,6 +121,8 @@ struct frt_renderer {
     std::vector<Timed> pending;
     std::vector<hipEvent_t> event_pool;
     // frame in progress
+    bool failed = false;                   // a HIP call failed in the middle of a frame: the stage flags and stream order are no longer trustworthy; render calls
+                                           // return FRT_ERR_STATE until frt_renderer_clear
     bool frame_open = false, g_done = false, tt_done = false, tm_done = false, s_started = false, s_inner_done = false, s_edge_done = false;
     bool from_speculation = false;
     Timed s_timer{};
@@ -438,7 +452,7 @@ static void free_queues(frt_renderer* r) {
 }
 void frt_renderer_destroy(frt_renderer* r) {
     if (!r) return;
-    (void)hipSetDevice(r->device);
+    DeviceGuard guard_(r->device);
     if (r->stream || r->own_stream) (void)hipStreamSynchronize(r->stream);
     if (r->ahead) { (void)hipStreamSynchronize(r->ahead); (void)hipStreamDestroy(r->ahead); }
     if (r->edge) { (void)hipStreamSynchronize(r->edge); (void)hipStreamDestroy(r->edge); }
@@ -513,7 +527,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(FRT_ERR_NO_DEVICE, "no HIP device: this library has no CPU rendering path");
     if (r->device < 0 || r->device >= ndev) return fail(FRT_ERR_INVALID_ARG, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(r->device));
+    FRT_DEVICE(r);
     if (o && (o->stream || (o->flags & FRT_FLAG_USE_STREAM))) { r->stream = (hipStream_t)o->stream; r->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); r->own_stream = true; }
     if ((r->flags & FRT_FLAG_PIPELINE) && !(r->flags & FRT_FLAG_COMPACTION)) {   // (the compacting kernels keep the fused temporal stage: nothing to run ahead)
@@ -802,11 +816,18 @@ static int launch_speculation(frt_renderer* r, const frt_camera_uniform* cam) {
     return FRT_OK;
 }
 
+static int render_phases_impl(frt_renderer* r, const frt_camera_uniform* cam, int phases);
 int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, int phases) {
     if (!r || !cam) return fail(FRT_ERR_INVALID_ARG, "render: null");
+    if (r->failed) return fail(FRT_ERR_STATE, "render: an earlier frame failed in the middle of its stages; call frt_renderer_clear");
+    const int rc = render_phases_impl(r, cam, phases);
+    if (rc == FRT_ERR_HIP) { r->failed = true; r->frame_open = false; }      // (argument errors are raised before anything is enqueued)
+    return rc;
+}
+static int render_phases_impl(frt_renderer* r, const frt_camera_uniform* cam, int phases) {
     if ((r->jitter[0] != 0.0f || r->jitter[1] != 0.0f) && !(r->rb == 0 && r->re == r->H) && (phases & FRT_PHASE_POST))
         return fail(FRT_ERR_INVALID_ARG, "render: a non-zero post jitter (bilinear taps with Repeat addressing) is not supported by strip renderers");
-    HIP_TRY(hipSetDevice(r->device));
+    FRT_DEVICE(r);
     if (!r->frame_open) { int rc = open_frame(r, cam); if (rc) return rc; }
     const bool timed = (r->flags & FRT_FLAG_TIMING) != 0;
     const bool compaction = (r->flags & FRT_FLAG_COMPACTION) != 0;
@@ -886,7 +907,9 @@ int frt_renderer_render_phases(frt_renderer* r, const frt_camera_uniform* cam, i
                 // the halo exchange (frt_renderer_stream(r, 2)); here it is ordered behind T-merge.
                 hipStream_t q = r->stream;
                 const bool any_edge = (ia > y0) || (y1 > ib);
-                if (r->edge && any_edge && ia < ib) { q = r->edge; HIP_TRY(hipStreamWaitEvent(r->edge, r->ev_tm[r->serial & 1u], 0)); }
+                // ALWAYS the edge stream when the renderer has one, also for a strip too thin to have interior rows: frt_renderer_stream(r, 2) names
+                // that stream unconditionally, and it is the only one the caller orders behind the arrival of the halo rows.
+                if (r->edge && any_edge) { q = r->edge; HIP_TRY(hipStreamWaitEvent(r->edge, r->ev_tm[r->serial & 1u], 0)); }
                 // A middle strip has two edges: the second launch goes to a stream of its own, ordered behind everything the edge stream holds
                 // so far (T-merge, the caller's exchange), so that the two run side by side (one after the other they cost a 1/8 strip 0.12 ms
                 // of its 0.52 ms frame: the spatial continuation waits for both).
@@ -958,12 +981,12 @@ int frt_renderer_render_jittered(frt_renderer* r, const frt_camera_uniform* cam,
 }
 int frt_renderer_sync(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "sync: null");
-    HIP_TRY(hipSetDevice(r->device));
+    FRT_DEVICE(r);
     return sync_all(r);
 }
 int frt_renderer_fence(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "fence: null");
-    HIP_TRY(hipSetDevice(r->device));
+    FRT_DEVICE(r);
     return fence_ahead(r);
 }
 void* frt_renderer_stream(const frt_renderer* r, int which) {
@@ -983,7 +1006,7 @@ int frt_renderer_reset(frt_renderer* r) {
 }
 int frt_renderer_clear(frt_renderer* r) {
     if (!r) return fail(FRT_ERR_INVALID_ARG, "clear: null");
-    HIP_TRY(hipSetDevice(r->device));
+    FRT_DEVICE(r);
     { int rc_ = sync_all(r); if (rc_) return rc_; }
     int rc = resolve_timing(r);
     if (rc) return rc;
@@ -996,6 +1019,7 @@ int frt_renderer_clear(frt_renderer* r) {
     rc = init_tile_state(r);
     if (rc) return rc;
     r->frame_count = 0;
+    r->failed = false;
     r->frame_open = false; r->specs.clear(); r->have_last_cam = false; r->camera_static = false;
     r->qparity[0] = r->qparity[1] = 0; r->logical_phys[0] = 0; r->logical_phys[1] = 1;
     r->cur_slots = r->last_slots = GSlots{0, 1, 0}; r->before_last_slots = GSlots{1, 0, 0};
@@ -1031,7 +1055,7 @@ int frt_renderer_buffer_info(const frt_renderer* r, int buf, int index, void** d
 int frt_renderer_read_buffer(frt_renderer* r, int buf, int index, void* out) {
     int b = r ? buf_index(r, buf, index) : -1;
     if (b < 0 || !out) return fail(FRT_ERR_INVALID_ARG, "read_buffer: bad arguments");
-    HIP_TRY(hipSetDevice(r->device));
+    FRT_DEVICE(r);
     { int rc_ = sync_all(r); if (rc_) return rc_; }
     HIP_TRY(hipMemcpy(out, r->buf(b), (size_t)r->W * r->H * bpp_of(b), hipMemcpyDeviceToHost));
     return FRT_OK;
@@ -1039,7 +1063,7 @@ int frt_renderer_read_buffer(frt_renderer* r, int buf, int index, void* out) {
 int frt_renderer_read_rows(frt_renderer* r, int buf, int index, uint32_t y0, uint32_t y1, void* out) {
     int b = r ? buf_index(r, buf, index) : -1;
     if (b < 0 || !out || y0 > y1 || y1 > r->H) return fail(FRT_ERR_INVALID_ARG, "read_rows: bad arguments");
-    HIP_TRY(hipSetDevice(r->device));
+    FRT_DEVICE(r);
     { int rc_ = sync_all(r); if (rc_) return rc_; }
     size_t pitch = (size_t)r->W * bpp_of(b);
     HIP_TRY(hipMemcpy(out, (uint8_t*)r->buf(b) + pitch * y0, pitch * (y1 - y0), hipMemcpyDeviceToHost));
@@ -1048,7 +1072,7 @@ int frt_renderer_read_rows(frt_renderer* r, int buf, int index, uint32_t y0, uin
 int frt_renderer_write_rows(frt_renderer* r, int buf, int index, uint32_t y0, uint32_t y1, const void* in) {
     int b = r ? buf_index(r, buf, index) : -1;
     if (b < 0 || !in || y0 > y1 || y1 > r->H) return fail(FRT_ERR_INVALID_ARG, "write_rows: bad arguments");
-    HIP_TRY(hipSetDevice(r->device));
+    FRT_DEVICE(r);
     { int rc_ = sync_all(r); if (rc_) return rc_; }
     size_t pitch = (size_t)r->W * bpp_of(b);
     HIP_TRY(hipMemcpy((uint8_t*)r->buf(b) + pitch * y0, in, pitch * (y1 - y0), hipMemcpyHostToDevice));
@@ -1067,7 +1091,7 @@ int frt_renderer_phase_rows(const frt_renderer* r, uint32_t out[8]) {
 }
 int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
     if (!r || !out) return fail(FRT_ERR_INVALID_ARG, "stats: null");
-    HIP_TRY(hipSetDevice(r->device));
+    FRT_DEVICE(r);
     { int rc_ = sync_all(r); if (rc_) return rc_; }
     int rc = resolve_timing(r);
     if (rc) return rc;

@@ -87,7 +87,10 @@ class ArenaRows:
         p, bpp = self.r.buffer_info(buf, index)
         pitch = self.r.width * bpp
         o = p - self.base + y0 * pitch
-        return self.arena[o:o + (y1 - y0) * pitch]
+        n = (y1 - y0) * pitch
+        if not (0 <= o and o + n <= self.arena.numel()):      # e.g. a strip renderer's third G-buffer set lives outside the caller's arena
+            raise ValueError(f"buffer {buf}[{index}] rows {y0}:{y1} do not lie inside the caller's arena (offset {o}, {n} bytes)")
+        return self.arena[o:o + n]
 
     def rows(self, buf, index, y0, y1):
         v = self._view(buf, index, y0, y1)

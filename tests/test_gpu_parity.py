@@ -499,3 +499,24 @@ def test_rccl_loopback_rehearsal_on_one_gpu(gpu):
     assert p.returncode == 0, p.stdout + p.stderr
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["ok"] and res["nccl"], res
+    # a strip too thin for interior rows: its edge launches are ordered behind the transfer on the edge stream
+    assert res["thin"]["rows_arrive"] and res["thin"]["async_equals_stepwise"], res
+
+
+def test_bench_self_launch_rehearsal_on_one_gpu(gpu):
+    """`python bench.py --gpus 2` from a bare shell (no RANK / WORLD_SIZE): bench.py starts its two ranks itself; both share this box's one
+    GPU over gloo (FRT_BENCH_ONE_GPU=1). One JSON line that names both ranks, their rows and devices."""
+    import json, subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FRT_BENCH_ONE_GPU"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--no-4k"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    cfg = res["config"]
+    assert res["n_gpus"] == 2 and cfg["process_group_world_size"] == 2 and cfg["allreduce_of_ones"] == 2 and cfg["self_launched"]
+    assert [r["rank"] for r in cfg["ranks"]] == [0, 1] and cfg["ranks"][0]["rows"][1] == cfg["ranks"][1]["rows"][0]
+    assert res["value"] > 0 and res["scaling"] == "strong"
