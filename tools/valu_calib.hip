@@ -14,7 +14,7 @@
 
 static constexpr int ITER = 8192;
 
-template <int K, bool DEP>
+template <int K, bool DEP, int LANES = 64>
 __global__ void __launch_bounds__(256) fma_kernel(float* out, unsigned long long* ticks, float b, float c) {
     extern __shared__ float s_pad[];      // dynamic LDS = 160 KiB / K: at most K workgroups (K waves per SIMD) fit on a CU
     if (b == 12345.0f) s_pad[threadIdx.x] = c;
@@ -23,6 +23,9 @@ __global__ void __launch_bounds__(256) fma_kernel(float* out, unsigned long long
     for (int i = 0; i < 16; ++i) a[i] = (float)(threadIdx.x + i);
     const unsigned long long w0 = wall_clock64();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    // LANES < 64: only the first LANES lanes of every wave run the loop (EXEC = the low lanes): does a wave64 instruction whose upper
+    // 32 lanes are all off still occupy the SIMD-32 for two passes?
+    if ((int)(threadIdx.x & 63) < LANES)
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -39,19 +42,19 @@ __global__ void __launch_bounds__(256) fma_kernel(float* out, unsigned long long
     if ((threadIdx.x & 63) == 0) { ticks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2] = t1 - t0; ticks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = w1 - w0; }
 }
 
-template <int K, bool DEP>
+template <int K, bool DEP, int LANES = 64>
 static void run(int cus, float* d_out, unsigned long long* d_ticks, double) {
     // ROUNDS x (cus x K) workgroups: the chip stays full (K resident workgroups per CU, LDS-limited) for ROUNDS generations, so
     // the event time / ROUNDS is the steady-state time of K waves per SIMD and uneven first placement washes out.
     const int ROUNDS = 6, grid = cus * K * ROUNDS;
     const size_t lds = (size_t)(160 * 1024) / K - 512;
-    hipFuncSetAttribute((const void*)fma_kernel<K, DEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)fma_kernel<K, DEP, LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((fma_kernel<K, DEP>), dim3(grid), dim3(256), lds, 0, d_out, d_ticks, 1.0000001f, 1e-9f);   // warm-up
+    hipLaunchKernelGGL((fma_kernel<K, DEP, LANES>), dim3(grid), dim3(256), lds, 0, d_out, d_ticks, 1.0000001f, 1e-9f);   // warm-up
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((fma_kernel<K, DEP>), dim3(grid), dim3(256), lds, 0, d_out, d_ticks, 1.0000001f, 1e-9f);
+    hipLaunchKernelGGL((fma_kernel<K, DEP, LANES>), dim3(grid), dim3(256), lds, 0, d_out, d_ticks, 1.0000001f, 1e-9f);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0.0f;
@@ -64,6 +67,7 @@ static void run(int cus, float* d_out, unsigned long long* d_ticks, double) {
     const double n_inst = (double)ITER * 16.0;           // wave-instructions per wave
     const double f_ghz = mhz[mhz.size() / 2] * 1e-3;     // shader clock while the kernel ran: s_memtime ticks per 100 MHz wall_clock64 tick
     const double simd_cycles = ms * 1e-3 * f_ghz * 1e9 / (n_inst * K * ROUNDS);
+    if (LANES < 64) printf("[first %d lanes only] ", LANES);
     printf("%s K=%d waves/SIMD (LDS-limited, %d rounds): shader clock %.3f GHz (s_memtime vs wall_clock64); a wave needs %.2f cycles per OWN instruction (median); "
            "event %.1f us -> %.2f SIMD cycles per wave-instruction\n",
            DEP ? "dependent  " : "independent", K, ROUNDS, f_ghz, own[own.size() / 2] / n_inst, ms * 1e3, simd_cycles);
@@ -86,6 +90,9 @@ int main() {
     run<1, true>(cus, d_out, d_ticks, ghz);
     run<2, true>(cus, d_out, d_ticks, ghz);
     run<4, true>(cus, d_out, d_ticks, ghz);
+    run<8, false, 32>(cus, d_out, d_ticks, ghz);
+    run<4, false, 32>(cus, d_out, d_ticks, ghz);
+    run<8, false, 16>(cus, d_out, d_ticks, ghz);
     hipFree(d_out); hipFree(d_ticks);
     return 0;
 }
