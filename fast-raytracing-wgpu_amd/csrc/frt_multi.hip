@@ -1,0 +1,331 @@
+// frt_multi.hip — N GPUs behind ONE call: frt_multi_renderer_* (include/frt.h).
+//
+// In the reference one call renders one frame (Renderer::render, src/renderer.rs:349-518, called from State::render, src/state.rs:192-204).
+// This is that call for a node with several GPUs: ONE process, `ndev` strip renderers (frt_renderer with a row range, two-stream schedule),
+// the scene replicated on every device, the frame cut into horizontal strips of equal WORK, and the three per-frame halo exchanges of
+// DESIGN.md §8 as peer copies (hipMemcpyPeerAsync over xGMI; a plain device-to-device copy when two strips share a device):
+//   "post"  1 row (K + 1 with a motion halo) of the previous frame's accumulation  -> the neighbour's halo rows, a whole frame ahead of its use
+//   "pre"   K rows of the previous frame's spatial reservoirs, before T-merge (moving camera only)
+//   "mid"   12 rows of this frame's temporal reservoirs, between T-merge and the spatial stage's EDGE rows (overlaps the interior rows)
+// The same six steps, in the same order and against the same streams, as frt/dist.py::render_strip_frame (the torch.distributed / RCCL form
+// of the loop); here every rank is a device of this process and the orderings are events:
+//   a copy runs on the DESTINATION strip's copy stream, behind (a) the event the SOURCE strip recorded after the kernel that produced the
+//   rows and (b) an event of the destination's own main stream that lies behind the last reader of the halo rows it overwrites;
+//   the consumer stream (main stream, or the edge stream for "mid") then waits for the copy's event.
+// Reads gather the strips' rows. Images are bit-identical to a single renderer's (tests: every logical device mapped to ordinal 0).
+#include "frt_scene.hpp"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace frt { int set_error(int code, const std::string& msg); }
+using frt::set_error;
+
+#define HIPM_TRY(expr)                                                                                       \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return set_error(FRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static const uint32_t kHaloReservoir = 12;   // spatial radius 10 + 2 rows of redundant spatial work (frt_renderer.hip: kHaloGbuffer)
+static const uint32_t kHaloHistory = 1;      // post reads the previous accumulation within +-1 row (post.wgsl:196-199)
+
+struct Strip {
+    int device = 0;
+    uint32_t rb = 0, re = 0;
+    frt_renderer* r = nullptr;
+    hipStream_t copy = nullptr;                       // this strip's incoming halo rows
+    hipEvent_t ev_tm = nullptr, ev_spatial = nullptr, ev_post = nullptr;      // recorded on the main stream behind T-merge / spatial / post of the current frame
+    hipEvent_t ev_copy_pre = nullptr, ev_copy_mid = nullptr, ev_copy_post = nullptr;
+};
+
+struct frt_multi_renderer {
+    uint32_t W = 0, H = 0, motion_halo = 0;
+    std::vector<Strip> strips;
+    std::vector<uint32_t> bounds;
+    uint32_t frame = 0;              // frames rendered since create / reset (== every strip's frame_count)
+    uint64_t serial = 0;             // frames rendered since create (never reset)
+};
+
+namespace {
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// Strip boundaries of equal WORK (the ceiling strip of a Cornell Box is far cheaper than the floor strip): a quarter-resolution probe
+// rendered band by band, exact device ray counters per band, cost = rays + 4 per pixel (frt/dist.py::balanced_boundaries, same numbers).
+int balanced_boundaries(const frt_scene* scene, uint32_t W, uint32_t H, uint32_t world, uint32_t max_depth, int device, uint32_t min_rows, std::vector<uint32_t>& out) {
+    out.assign(1, 0u);
+    if (world == 1) { out.push_back(H); return FRT_OK; }
+    const uint32_t bands = 36, probe_frames = 2;
+    const uint32_t pw = std::max(W / 4u, 16u), ph = std::max(H / 4u, bands);
+    std::vector<double> cost(bands, 0.0);
+    uint32_t counts[8];
+    if (frt_scene_counts(scene, counts) != FRT_OK) return FRT_ERR_INVALID_ARG;
+    for (uint32_t b = 0; b < bands; ++b) {
+        const uint32_t y0 = ph * b / bands, y1 = ph * (b + 1) / bands;
+        frt_render_opts o{};
+        o.max_depth = max_depth; o.device = device; o.row_begin = y0; o.row_end = y1;
+        frt_renderer* r = frt_renderer_create(scene, pw, ph, &o);
+        if (!r) return FRT_ERR_HIP;
+        for (uint32_t f = 0; f < probe_frames; ++f) {
+            frt_camera_uniform cam;
+            frt_camera_default((float)W / (float)H, f, counts[3], &cam);
+            const int rc = frt_renderer_render(r, &cam);
+            if (rc) { frt_renderer_destroy(r); return rc; }
+        }
+        frt_stats st;
+        const int rc = frt_renderer_stats(r, &st);
+        frt_renderer_destroy(r);
+        if (rc) return rc;
+        cost[b] = (double)(st.rays_closest + st.rays_any) + 4.0 * pw * (y1 - y0) * probe_frames;
+    }
+    std::vector<double> cum(H + 1, 0.0);
+    for (uint32_t b = 0; b < bands; ++b) {
+        const uint32_t y0 = H * b / bands, y1 = H * (b + 1) / bands;
+        for (uint32_t y = y0; y < y1; ++y) cum[y + 1] = cost[b] / std::max(y1 - y0, 1u);
+    }
+    for (uint32_t y = 0; y < H; ++y) cum[y + 1] += cum[y];
+    for (uint32_t k = 1; k < world; ++k) {
+        const double target = cum[H] * k / world;
+        uint32_t y = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        y = std::max(y, out.back() + min_rows);                         // every strip at least as tall as the halo
+        y = std::min(y, H - min_rows * (world - k));
+        out.push_back(y);
+    }
+    out.push_back(H);
+    return FRT_OK;
+}
+
+uint32_t bpp_of_buf(int buf) {
+    switch (buf) {
+    case FRT_BUF_GPOS: case FRT_BUF_GNORMAL: case FRT_BUF_ACCUM: case FRT_BUF_CANDIDATE: return 16u;
+    case FRT_BUF_GALBEDO: case FRT_BUF_DISPLAY: return 4u;
+    case FRT_BUF_GMOTION: case FRT_BUF_RAW: return 8u;
+    case FRT_BUF_RESERVOIR: return 32u;
+    }
+    return 0u;
+}
+
+// rows [y0, y1) of `buf`[index]: from strip `src` into the same image rows of strip `dst`, on dst's copy stream
+int copy_rows(frt_multi_renderer* m, Strip& src, Strip& dst, int buf, int index, uint32_t y0, uint32_t y1) {
+    void *ps = nullptr, *pd = nullptr;
+    uint32_t bpp = 0;
+    int rc = frt_renderer_buffer_info(src.r, buf, index, &ps, &bpp);
+    if (rc) return rc;
+    rc = frt_renderer_buffer_info(dst.r, buf, index, &pd, &bpp);
+    if (rc) return rc;
+    const size_t pitch = (size_t)m->W * bpp, off = pitch * y0, bytes = pitch * (y1 - y0);
+    if (src.device == dst.device) HIPM_TRY(hipMemcpyAsync((uint8_t*)pd + off, (const uint8_t*)ps + off, bytes, hipMemcpyDeviceToDevice, dst.copy));
+    else HIPM_TRY(hipMemcpyPeerAsync((uint8_t*)pd + off, dst.device, (const uint8_t*)ps + off, src.device, bytes, dst.copy));
+    return FRT_OK;
+}
+
+// One exchange with both vertical neighbours: strip k receives `rows` rows from each neighbour into the rows just outside its own.
+// src_ev(strip): the event behind the kernel that produced the rows; dst_ev(strip): an event of the receiver's main stream behind the last
+// reader of the halo rows; done(strip): the event recorded behind the strip's incoming copies.
+enum Which { PRE, MID, POST };
+int exchange(frt_multi_renderer* m, Which which, int buf, int index, uint32_t rows) {
+    const size_t n = m->strips.size();
+    for (size_t k = 0; k < n; ++k) {
+        Strip& d = m->strips[k];
+        DevGuard g(d.device);
+        hipEvent_t own = which == MID ? d.ev_tm : (which == PRE ? d.ev_spatial : d.ev_post);
+        hipEvent_t done = which == MID ? d.ev_copy_mid : (which == PRE ? d.ev_copy_pre : d.ev_copy_post);
+        HIPM_TRY(hipStreamWaitEvent(d.copy, own, 0));
+        for (int side = 0; side < 2; ++side) {
+            if ((side == 0 && k == 0) || (side == 1 && k + 1 == n)) continue;
+            Strip& s = m->strips[side == 0 ? k - 1 : k + 1];
+            hipEvent_t produced = which == MID ? s.ev_tm : (which == PRE ? s.ev_spatial : s.ev_post);
+            HIPM_TRY(hipStreamWaitEvent(d.copy, produced, 0));
+            // the upper neighbour's last `rows` rows land in [rb - rows, rb); the lower neighbour's first `rows` rows in [re, re + rows)
+            const uint32_t y0 = side == 0 ? d.rb - rows : d.re, y1 = side == 0 ? d.rb : d.re + rows;
+            const int rc = copy_rows(m, s, d, buf, index, y0, y1);
+            if (rc) return rc;
+        }
+        HIPM_TRY(hipEventRecord(done, d.copy));
+    }
+    return FRT_OK;
+}
+}   // namespace
+
+extern "C" {
+
+frt_multi_renderer* frt_multi_renderer_create(const frt_scene* scene, uint32_t width, uint32_t height, uint32_t ndev, const int32_t* devices, const frt_render_opts* opts) {
+    if (!scene || width == 0 || height == 0 || ndev == 0) { set_error(FRT_ERR_INVALID_ARG, "multi_renderer_create: bad arguments"); return nullptr; }
+    const int have = frt_device_count();
+    if (have < 1) { set_error(FRT_ERR_NO_DEVICE, "no HIP device: this library has no CPU rendering path"); return nullptr; }
+    std::vector<int> dev(ndev);
+    for (uint32_t k = 0; k < ndev; ++k) {
+        dev[k] = devices ? devices[k] : (int)k;
+        if (dev[k] < 0 || dev[k] >= have) { set_error(FRT_ERR_INVALID_ARG, "multi_renderer_create: device ordinal out of range"); return nullptr; }
+    }
+    const uint32_t max_depth = (opts && opts->max_depth) ? opts->max_depth : 8u;
+    const uint32_t K = opts ? opts->motion_halo_rows : 0u;
+    const uint32_t need = std::max(kHaloReservoir, K + kHaloHistory);
+    if (ndev > 1 && height / ndev < need) { set_error(FRT_ERR_INVALID_ARG, "multi_renderer_create: strips would be thinner than the halo"); return nullptr; }
+    frt_multi_renderer* m = new frt_multi_renderer();
+    m->W = width; m->H = height; m->motion_halo = K;
+    if (balanced_boundaries(scene, width, height, ndev, max_depth, dev[0], need, m->bounds) != FRT_OK) {
+        m->bounds.clear();      // equal strips are always valid; balancing is an optimisation
+        for (uint32_t k = 0; k <= ndev; ++k) m->bounds.push_back((uint32_t)((uint64_t)height * k / ndev));
+    }
+    m->strips.resize(ndev);
+    for (uint32_t k = 0; k < ndev; ++k) {
+        Strip& s = m->strips[k];
+        s.device = dev[k]; s.rb = m->bounds[k]; s.re = m->bounds[k + 1];
+        frt_render_opts o{};
+        o.max_depth = max_depth; o.device = dev[k]; o.flags = FRT_FLAG_PIPELINE | (opts ? (opts->flags & FRT_FLAG_TIMING) : 0u);
+        o.queue_capacity = opts ? opts->queue_capacity : 0u;
+        if (ndev > 1) { o.row_begin = s.rb; o.row_end = s.re; o.motion_halo_rows = K; }
+        s.r = frt_renderer_create(scene, width, height, &o);
+        if (!s.r) { frt_multi_renderer_destroy(m); return nullptr; }
+        DevGuard g(s.device);
+        bool ok = hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking) == hipSuccess;
+        for (hipEvent_t* e : {&s.ev_tm, &s.ev_spatial, &s.ev_post, &s.ev_copy_pre, &s.ev_copy_mid, &s.ev_copy_post})
+            ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { set_error(FRT_ERR_HIP, "multi_renderer_create: stream / event creation failed"); frt_multi_renderer_destroy(m); return nullptr; }
+    }
+    // peer access between neighbouring strips on different devices (hipMemcpyPeerAsync works without it, through a staging buffer; with it
+    // the rows go straight over xGMI)
+    for (uint32_t k = 0; k + 1 < ndev; ++k) {
+        const int a = dev[k], b = dev[k + 1];
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) { DevGuard g(a); (void)hipDeviceEnablePeerAccess(b, 0); }
+        if (hipDeviceCanAccessPeer(&can, b, a) == hipSuccess && can) { DevGuard g(b); (void)hipDeviceEnablePeerAccess(a, 0); }
+        (void)hipGetLastError();      // "already enabled" is not an error here
+    }
+    return m;
+}
+
+void frt_multi_renderer_destroy(frt_multi_renderer* m) {
+    if (!m) return;
+    for (Strip& s : m->strips) {
+        DevGuard g(s.device);
+        if (s.r) (void)frt_renderer_sync(s.r);
+        if (s.copy) { (void)hipStreamSynchronize(s.copy); (void)hipStreamDestroy(s.copy); }
+        for (hipEvent_t e : {s.ev_tm, s.ev_spatial, s.ev_post, s.ev_copy_pre, s.ev_copy_mid, s.ev_copy_post}) if (e) (void)hipEventDestroy(e);
+        if (s.r) frt_renderer_destroy(s.r);
+    }
+    delete m;
+}
+
+// Renderer::render, src/renderer.rs:349 — ONE call, one frame, on every device. Asynchronous.
+int frt_multi_renderer_render(frt_multi_renderer* m, const frt_camera_uniform* cam) {
+    if (!m || !cam) return set_error(FRT_ERR_INVALID_ARG, "multi render: null");
+    const size_t n = m->strips.size();
+    if (n == 1) { const int rc = frt_renderer_render(m->strips[0].r, cam); if (rc == FRT_OK) { m->frame += 1; m->serial += 1; } return rc; }
+    const uint32_t K = m->motion_halo;
+    const bool first = m->serial == 0;      // nothing of a previous frame exists yet (events unrecorded, buffers zero)
+    int rc;
+    // "post": the previous frame's accumulation rows (source: post(f-1)); a whole frame of slack. "pre": previous spatial reservoirs.
+    if (!first && m->frame > 0) {
+        rc = exchange(m, POST, FRT_BUF_ACCUM, (int)((m->frame - 1u) & 1u), K ? K + kHaloHistory : kHaloHistory);
+        if (rc) return rc;
+        if (K) { rc = exchange(m, PRE, FRT_BUF_RESERVOIR, 1, K); if (rc) return rc; }
+    }
+    for (Strip& s : m->strips) {      // G-buffer + T-trace (normally already done, ahead of the frame) and T-merge
+        DevGuard g(s.device);
+        hipStream_t q = (hipStream_t)frt_renderer_stream(s.r, 0);
+        if (!first && m->frame > 0 && K) HIPM_TRY(hipStreamWaitEvent(q, s.ev_copy_pre, 0));
+        rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_GBUFFER | FRT_PHASE_TEMPORAL);
+        if (rc) return rc;
+        HIPM_TRY(hipEventRecord(s.ev_tm, q));
+    }
+    rc = exchange(m, MID, FRT_BUF_RESERVOIR, 0, kHaloReservoir);      // behind every strip's T-merge
+    if (rc) return rc;
+    for (Strip& s : m->strips) {      // interior rows: need nothing from a neighbour
+        rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_SPATIAL_INNER);
+        if (rc) return rc;
+    }
+    for (Strip& s : m->strips) {      // edge rows (their own stream, behind the arrival of the neighbours' reservoirs) + continuations
+        DevGuard g(s.device);
+        HIPM_TRY(hipStreamWaitEvent((hipStream_t)frt_renderer_stream(s.r, 2), s.ev_copy_mid, 0));
+        rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_SPATIAL_EDGE);
+        if (rc) return rc;
+        HIPM_TRY(hipEventRecord(s.ev_spatial, (hipStream_t)frt_renderer_stream(s.r, 0)));
+    }
+    for (Strip& s : m->strips) {
+        DevGuard g(s.device);
+        hipStream_t q = (hipStream_t)frt_renderer_stream(s.r, 0);
+        if (!first && m->frame > 0) HIPM_TRY(hipStreamWaitEvent(q, s.ev_copy_post, 0));
+        rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_POST);
+        if (rc) return rc;
+        HIPM_TRY(hipEventRecord(s.ev_post, q));
+        rc = frt_renderer_end_frame(s.r);
+        if (rc) return rc;
+    }
+    m->frame += 1; m->serial += 1;
+    return FRT_OK;
+}
+
+int frt_multi_renderer_sync(frt_multi_renderer* m) {
+    if (!m) return set_error(FRT_ERR_INVALID_ARG, "multi sync: null");
+    for (Strip& s : m->strips) {
+        int rc = frt_renderer_sync(s.r);
+        if (rc) return rc;
+        DevGuard g(s.device);
+        HIPM_TRY(hipStreamSynchronize(s.copy));
+    }
+    return FRT_OK;
+}
+
+uint32_t frt_multi_renderer_frame_count(const frt_multi_renderer* m) { return m ? m->frame : 0u; }
+
+int frt_multi_renderer_reset(frt_multi_renderer* m) {      // frame_count = 0 (state.rs:152): buffers keep their contents
+    if (!m) return set_error(FRT_ERR_INVALID_ARG, "multi reset: null");
+    for (Strip& s : m->strips) { int rc = frt_renderer_reset(s.r); if (rc) return rc; }
+    m->frame = 0;
+    return FRT_OK;
+}
+
+int frt_multi_renderer_boundaries(const frt_multi_renderer* m, uint32_t* out) {
+    if (!m || !out) return set_error(FRT_ERR_INVALID_ARG, "multi boundaries: null");
+    memcpy(out, m->bounds.data(), m->bounds.size() * sizeof(uint32_t));
+    return (int)m->strips.size();
+}
+
+// Gather: every strip's own rows of a target into one full-frame host buffer.
+int frt_multi_renderer_read_buffer(frt_multi_renderer* m, int buf, int index, void* out) {
+    const uint32_t bpp = bpp_of_buf(buf);
+    if (!m || !out || !bpp) return set_error(FRT_ERR_INVALID_ARG, "multi read_buffer: bad arguments");
+    int rc = frt_multi_renderer_sync(m);
+    if (rc) return rc;
+    for (Strip& s : m->strips) {
+        rc = frt_renderer_read_rows(s.r, buf, index, s.rb, s.re, (uint8_t*)out + (size_t)m->W * bpp * s.rb);
+        if (rc) return rc;
+    }
+    return FRT_OK;
+}
+int frt_multi_renderer_read_display(frt_multi_renderer* m, uint8_t* rgba8) { return frt_multi_renderer_read_buffer(m, FRT_BUF_DISPLAY, 0, rgba8); }
+int frt_multi_renderer_read_accum(frt_multi_renderer* m, float* rgba32f) {
+    if (!m) return set_error(FRT_ERR_INVALID_ARG, "multi read_accum: null");
+    return frt_multi_renderer_read_buffer(m, FRT_BUF_ACCUM, m->frame ? (int)((m->frame - 1u) & 1u) : 0, rgba32f);
+}
+
+// Sums over the strips (rays are counted only for rows a strip owns, so the totals are those of a single renderer).
+int frt_multi_renderer_stats(frt_multi_renderer* m, frt_stats* out) {
+    if (!m || !out) return set_error(FRT_ERR_INVALID_ARG, "multi stats: null");
+    frt_stats t{};
+    for (Strip& s : m->strips) {
+        frt_stats st;
+        int rc = frt_renderer_stats(s.r, &st);
+        if (rc) return rc;
+        t.rays_closest += st.rays_closest; t.rays_any += st.rays_any;
+        t.frames = std::max(t.frames, st.frames);
+        for (int i = 0; i < 4; ++i) { t.ms_stage[i] = std::max(t.ms_stage[i], st.ms_stage[i]); t.launches[i] += st.launches[i]; t.rays_stage[i][0] += st.rays_stage[i][0]; t.rays_stage[i][1] += st.rays_stage[i][1]; }
+        t.halo_overflow += st.halo_overflow; t.ms_merge = std::max(t.ms_merge, st.ms_merge); t.queue_overflow += st.queue_overflow;
+        t.queue_capacity = std::max(t.queue_capacity, st.queue_capacity); t.speculated_frames += st.speculated_frames;
+        t.discarded_speculations += st.discarded_speculations; t.queue_bytes += st.queue_bytes;
+    }
+    *out = t;
+    return FRT_OK;
+}
+
+}   // extern "C"

@@ -16,4 +16,4 @@ from ._lib import (FLAG_TIMING, FLAG_COMPACTION, FLAG_USE_STREAM, FLAG_OVERLAP_P
 from . import geometry, scenes, loader  # noqa: F401
 from .scene import SceneBuilder, material_new  # noqa: F401
 from .camera import CameraController  # noqa: F401
-from .renderer import Renderer  # noqa: F401
+from .renderer import Renderer, MultiRenderer  # noqa: F401

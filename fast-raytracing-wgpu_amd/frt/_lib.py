@@ -119,6 +119,17 @@ SYMBOLS = {
     "frt_renderer_phase_rows": (C.c_int, [_P, _P]),
     "frt_renderer_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "frt_renderer_set_timing": (C.c_int, [_P, C.c_int]),
+    "frt_multi_renderer_create": (_P, [_P, _U32, _U32, _U32, _P, C.POINTER(RenderOpts)]),
+    "frt_multi_renderer_destroy": (None, [_P]),
+    "frt_multi_renderer_render": (C.c_int, [_P, C.POINTER(CameraUniform)]),
+    "frt_multi_renderer_sync": (C.c_int, [_P]),
+    "frt_multi_renderer_frame_count": (_U32, [_P]),
+    "frt_multi_renderer_reset": (C.c_int, [_P]),
+    "frt_multi_renderer_read_display": (C.c_int, [_P, _P]),
+    "frt_multi_renderer_read_accum": (C.c_int, [_P, _P]),
+    "frt_multi_renderer_read_buffer": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "frt_multi_renderer_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "frt_multi_renderer_boundaries": (C.c_int, [_P, _P]),
 }
 
 _lib = None

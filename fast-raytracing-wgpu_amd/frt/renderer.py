@@ -119,3 +119,70 @@ class Renderer:
                 "rays_stage": [[int(s.rays_stage[i][0]), int(s.rays_stage[i][1])] for i in range(4)], "halo_overflow": int(s.halo_overflow),
                 "ms_merge": s.ms_merge, "queue_overflow": int(s.queue_overflow), "queue_capacity": int(s.queue_capacity), "queue_bytes": int(s.queue_bytes),
                 "speculated_frames": int(s.speculated_frames), "discarded_speculations": int(s.discarded_speculations)}
+
+
+def _stats_dict(s):
+    return {"rays_closest": s.rays_closest, "rays_any": s.rays_any, "frames": s.frames,
+            "ms_stage": list(s.ms_stage), "launches": list(s.launches),
+            "rays_stage": [[int(s.rays_stage[i][0]), int(s.rays_stage[i][1])] for i in range(4)], "halo_overflow": int(s.halo_overflow),
+            "ms_merge": s.ms_merge, "queue_overflow": int(s.queue_overflow), "queue_capacity": int(s.queue_capacity), "queue_bytes": int(s.queue_bytes),
+            "speculated_frames": int(s.speculated_frames), "discarded_speculations": int(s.discarded_speculations)}
+
+
+class MultiRenderer:
+    """Renderer::new / render (renderer.rs:206, :349) for several GPUs of one node through frt_multi_renderer_*: ONE process, one call per
+    frame; strips, halo copies and the gather are inside libfrt.so. `devices`: HIP ordinals, repeats allowed (several strips on one GPU)."""
+
+    def __init__(self, scene, width, height, devices, max_depth=8, motion_halo=0, flags=0, queue_capacity=0):
+        o = RenderOpts()
+        o.max_depth, o.flags, o.motion_halo_rows, o.queue_capacity = max_depth, flags, motion_halo, queue_capacity
+        dev = (C.c_int32 * len(devices))(*devices)
+        self.width, self.height, self.ndev = width, height, len(devices)
+        self._scene = scene
+        self._destroy = lib().frt_multi_renderer_destroy
+        self._h = lib().frt_multi_renderer_create(scene._h, width, height, len(devices), dev, C.byref(o))
+        if not self._h:
+            raise FrtError("multi renderer creation failed: " + lib().frt_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._destroy(self._h)
+            self._h = None
+
+    @property
+    def frame_count(self):
+        return int(lib().frt_multi_renderer_frame_count(self._h))
+
+    def render(self, camera_uniform):
+        check(lib().frt_multi_renderer_render(self._h, C.byref(camera_uniform)))
+
+    def sync(self):
+        check(lib().frt_multi_renderer_sync(self._h))
+
+    def reset(self):
+        check(lib().frt_multi_renderer_reset(self._h))
+
+    def boundaries(self):
+        out = (C.c_uint32 * (self.ndev + 1))()
+        check(lib().frt_multi_renderer_boundaries(self._h, out))
+        return list(out)
+
+    def read_buffer(self, buf, index=0):
+        out = np.zeros((self.height, self.width, BUF_BPP[buf]), np.uint8)
+        check(lib().frt_multi_renderer_read_buffer(self._h, buf, index, out.ctypes.data))
+        return out
+
+    def read_display(self):
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        check(lib().frt_multi_renderer_read_display(self._h, out.ctypes.data))
+        return out
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        check(lib().frt_multi_renderer_read_accum(self._h, out.ctypes.data))
+        return out
+
+    def stats(self):
+        s = Stats()
+        check(lib().frt_multi_renderer_stats(self._h, C.byref(s)))
+        return _stats_dict(s)

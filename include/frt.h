@@ -262,6 +262,29 @@ int frt_renderer_stats(frt_renderer* r, frt_stats* out);      /* syncs first */
 /* Switch FRT_FLAG_TIMING on or off after creation (the per-stage HIP events cost ~25 us per frame: too much for a thin strip) */
 int frt_renderer_set_timing(frt_renderer* r, int on);
 
+/* ---- N GPUs behind one call (`ngpus`; section 8e) -----------------------------------------------------------------
+ * In the reference one call renders one frame: Renderer::render, src/renderer.rs:349-518, called from State::render, src/state.rs:192-204.
+ * frt_multi_renderer is that call for a node with several GPUs: ONE process, `ndev` strip renderers (two-stream schedule), the scene
+ * replicated on every device, the frame cut into horizontal strips of equal work, the per-frame halo rows moved by peer copies
+ * (hipMemcpyPeerAsync over xGMI) on the right streams, the image gathered when it is read. A Rust `Renderer` over this handle gets N GPUs
+ * without knowing about strips. Images are bit-identical to a single frt_renderer's.
+ * devices: `ndev` HIP ordinals (NULL = 0 .. ndev-1); an ordinal may repeat (several strips on one GPU: how the path is tested on a 1-GPU box).
+ * opts: max_depth, motion_halo_rows (moving camera: rows of previous-frame state exchanged around every strip), queue_capacity and
+ * FRT_FLAG_TIMING are honoured; device, stream, rows and arena are set per strip by the library. */
+typedef struct frt_multi_renderer frt_multi_renderer;
+frt_multi_renderer* frt_multi_renderer_create(const frt_scene* s, uint32_t width, uint32_t height, uint32_t ndev, const int32_t* devices,
+                                              const frt_render_opts* opts);                       /* Renderer::new, src/renderer.rs:206 */
+void frt_multi_renderer_destroy(frt_multi_renderer* m);
+int frt_multi_renderer_render(frt_multi_renderer* m, const frt_camera_uniform* cam);              /* Renderer::render, :349 — asynchronous */
+int frt_multi_renderer_sync(frt_multi_renderer* m);
+uint32_t frt_multi_renderer_frame_count(const frt_multi_renderer* m);                             /* renderer.frame_count, :198 */
+int frt_multi_renderer_reset(frt_multi_renderer* m);                                              /* frame_count = 0, state.rs:152 */
+int frt_multi_renderer_read_display(frt_multi_renderer* m, uint8_t* rgba8);                       /* post_processed_texture, state.rs:226-278 (gathers the strips) */
+int frt_multi_renderer_read_accum(frt_multi_renderer* m, float* rgba32f);
+int frt_multi_renderer_read_buffer(frt_multi_renderer* m, int buf, int index, void* out);         /* any target, every strip's own rows */
+int frt_multi_renderer_stats(frt_multi_renderer* m, frt_stats* out);                              /* summed over the strips */
+int frt_multi_renderer_boundaries(const frt_multi_renderer* m, uint32_t* rows_out);               /* ndev + 1 row indices; returns ndev */
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,3 +79,10 @@ def test_product_does_not_link_the_oracle():
                 assert "oracle/" not in text and "liborc" not in text and "orc_" not in text, os.path.join(d, f)
     out = os.popen(f"ldd {os.path.join(pkg, 'lib', 'libfrt.so')}").read()
     assert "liborc" not in out and "hostcheck" not in out
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_multi_renderer_has_no_cpu_fallback_either(frt):
+    s = frt.scenes.create_cornell_box()
+    with pytest.raises(frt.FrtError, match="no HIP device"):
+        frt.MultiRenderer(s, 64, 64, [0, 1])

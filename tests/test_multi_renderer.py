@@ -1,0 +1,99 @@
+"""frt_multi_renderer (include/frt.h): N GPUs behind ONE render call, through the C ABI alone (no torch.distributed, no Python frame loop).
+On the one-GPU test box every logical device is ordinal 0: `ndev` strip renderers share the card, the halo rows move by device-to-device
+copies on the streams and events the library sets up, and the gathered image must equal a single renderer's bit for bit."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(frt):
+    if frt.lib().frt_device_count() < 1:
+        pytest.skip("no HIP device")
+    return frt
+
+
+BUFS = ("BUF_RESERVOIR0", "BUF_RESERVOIR1", "BUF_RAW", "BUF_DISPLAY", "BUF_ACCUM0", "BUF_ACCUM1")
+
+
+def _read_all(frt, r):
+    out = {}
+    for name, (buf, idx) in {"res0": (frt.BUF_RESERVOIR, 0), "res1": (frt.BUF_RESERVOIR, 1), "raw": (frt.BUF_RAW, 0), "display": (frt.BUF_DISPLAY, 0),
+                             "acc0": (frt.BUF_ACCUM, 0), "acc1": (frt.BUF_ACCUM, 1)}.items():
+        out[name] = r.read_buffer(buf, idx)
+    return out
+
+
+@pytest.mark.parametrize("ndev,W,H,frames", [(4, 320, 200, 6), (3, 160, 96, 5), (1, 96, 64, 3), (8, 480, 270, 4)])
+def test_multi_equals_single_static_camera(gpu, ndev, W, H, frames):
+    frt = gpu
+    scene = frt.scenes.create_cornell_box()
+    cams = [frt.CameraController().build_uniform(W / H, f, scene.num_lights) for f in range(frames)]
+    one = frt.Renderer(scene, W, H, flags=frt.FLAG_PIPELINE)
+    multi = frt.MultiRenderer(scene, W, H, [0] * ndev)
+    b = multi.boundaries()
+    assert b[0] == 0 and b[-1] == H and all(y1 - y0 >= 12 for y0, y1 in zip(b, b[1:])) or ndev == 1
+    for f in range(frames):
+        one.render(cams[f]); multi.render(cams[f])
+        assert multi.frame_count == one.frame_count == f + 1
+        got, want = _read_all(frt, multi), _read_all(frt, one)       # (reads sync: also a frame boundary with nothing in flight)
+        for k in got:
+            assert got[k].tobytes() == want[k].tobytes(), f"frame {f}: {k} differs ({ndev} strips {b})"
+    s1, sm = one.stats(), multi.stats()
+    assert (sm["rays_closest"], sm["rays_any"]) == (s1["rays_closest"], s1["rays_any"])
+    assert sm["halo_overflow"] == 0
+    assert np.array_equal(multi.read_accum(), one.read_accum()) and np.array_equal(multi.read_display(), one.read_display())
+
+
+def test_multi_without_reads_between_frames(gpu):
+    """The asynchronous path: 12 frames enqueued back to back (speculated next frames, copies and kernels in flight together), one read at the end."""
+    frt = gpu
+    W, H, N = 640, 360, 12
+    scene = frt.scenes.create_cornell_box()
+    cams = [frt.CameraController().build_uniform(W / H, f, scene.num_lights) for f in range(N)]
+    one = frt.Renderer(scene, W, H, flags=frt.FLAG_PIPELINE)
+    multi = frt.MultiRenderer(scene, W, H, [0, 0, 0, 0])
+    for f in range(N):
+        one.render(cams[f]); multi.render(cams[f])
+    got, want = _read_all(frt, multi), _read_all(frt, one)
+    for k in got:
+        assert got[k].tobytes() == want[k].tobytes(), k
+    assert multi.stats()["speculated_frames"] > 0
+
+
+def test_multi_moving_camera(gpu):
+    """SURVEY §8f-2 through the multi-device handle: reprojection and history fetches cross strip boundaries; motion_halo rows of the
+    previous frame's spatial reservoirs ("pre") and accumulation ("post") are exchanged around every strip."""
+    frt = gpu
+    import _scenes
+    W, H, N, K = 320, 192, 6, 8
+    scene = frt.scenes.create_cornell_box()
+    cams = _scenes.moving_camera_uniforms(frt, W / H, scene.num_lights, N)
+    one = frt.Renderer(scene, W, H, flags=frt.FLAG_PIPELINE)
+    multi = frt.MultiRenderer(scene, W, H, [0, 0, 0], motion_halo=K)
+    for f in range(N):
+        one.render(cams[f]); multi.render(cams[f])
+    got, want = _read_all(frt, multi), _read_all(frt, one)
+    for k in got:
+        assert got[k].tobytes() == want[k].tobytes(), k
+    assert multi.stats()["halo_overflow"] == 0
+
+
+def test_multi_reset_and_errors(gpu):
+    frt = gpu
+    W, H = 160, 96
+    scene = frt.scenes.create_cornell_box()
+    cams = [frt.CameraController().build_uniform(W / H, f, scene.num_lights) for f in range(3)]
+    one = frt.Renderer(scene, W, H, flags=frt.FLAG_PIPELINE)
+    multi = frt.MultiRenderer(scene, W, H, [0, 0])
+    for r in (one, multi):
+        r.render(cams[0]); r.render(cams[1]); r.reset()
+        assert r.frame_count == 0
+        r.render(cams[0]); r.render(cams[1])         # frame_count restarts, buffers keep their contents (state.rs:152)
+    assert np.array_equal(multi.read_accum(), one.read_accum())
+    with pytest.raises(frt.FrtError):
+        frt.MultiRenderer(scene, W, H, [0, 99])          # device ordinal out of range
+    with pytest.raises(frt.FrtError):
+        frt.MultiRenderer(scene, 64, 40, [0] * 8)       # strips thinner than the halo
