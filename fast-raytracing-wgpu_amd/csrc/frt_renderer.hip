@@ -10,6 +10,10 @@
 #include <vector>
 #include <cstdlib>
 
+#ifndef FRT_EXPERIMENTS
+#define FRT_EXPERIMENTS 0      // 1: lib/libfrt_exp.so (`make experiments`): the measured-and-not-kept kernel designs and their FRT_* environment knobs
+#endif
+
 using namespace frt;
 
 static thread_local std::string g_err;
@@ -485,7 +489,9 @@ static int alloc_queues(frt_renderer* r, uint32_t cap) {
     free_queues(r);
     r->qcap = cap;
     if (!stage_is_cut(r) || cap == 0) return FRT_OK;
+    r->qbytes = 0;
     if (r->wavefront) {
+        r->qbytes = (uint64_t)2 * (2 * 44 + 2 * 2 + 7) * cap * sizeof(uint32_t);
         for (auto& q : r->qslots) q[0] = q[1] = cap;
         for (int st = 0; st < 2; ++st) {
             for (int k = 0; k < 2; ++k) {
@@ -502,7 +508,6 @@ static int alloc_queues(frt_renderer* r, uint32_t cap) {
     // they are grown together. A capacity given by the caller applies to all four.
     const int nbuf = r->ncuts >= 2 ? 2 : 1;
     static const double kShare[2][2] = {{0.65, 0.3}, {1.0, 0.6}};
-    r->qbytes = 0;
     for (int st = 0; st < 2; ++st)
         for (int k = 0; k < 2; ++k) {
             r->qslots[st][k] = (r->qcap_fixed || cap >= r->qcap_max) ? cap : std::min(cap, std::max(4096u, (uint32_t)(kShare[st][k] * cap)));
@@ -534,17 +539,25 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         int prio = (lo + hi) / 2;
-        if (const char* e = getenv("FRT_AHEAD_PRIO")) prio = !strcmp(e, "low") ? lo : (!strcmp(e, "high") ? hi : prio);   // experiment knob
+#if FRT_EXPERIMENTS
+        if (const char* e = getenv("FRT_AHEAD_PRIO")) prio = !strcmp(e, "low") ? lo : (!strcmp(e, "high") ? hi : prio);
+#endif
         HIP_TRY(hipStreamCreateWithPriority(&r->ahead, hipStreamNonBlocking, prio));
         HIP_TRY(hipStreamCreateWithPriority(&r->edge, hipStreamNonBlocking, prio));
         if (r->rb > 0 && r->re < r->H) HIP_TRY(hipStreamCreateWithPriority(&r->edge2, hipStreamNonBlocking, prio));   // a middle strip has two edges
         for (hipEvent_t* e : {&r->ev_spix, &r->ev_tail, &r->ev_tm[0], &r->ev_tm[1], &r->ev_edge, &r->ev_edge2, &r->ev_edge_ready}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
         for (hipEvent_t& e : r->ev_tt) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        if (const char* e = getenv("FRT_SPEC_DEPTH")) r->spec_depth = std::max(0, std::min(kSpecDepth, atoi(e)));   // experiment knob
+#if FRT_EXPERIMENTS
+        if (const char* e = getenv("FRT_SPEC_DEPTH")) r->spec_depth = std::max(0, std::min(kSpecDepth, atoi(e)));
+#endif
     }
     r->arena_bytes = arena_layout(r->W, r->H, r->off);
-    // (experiment / test knobs: FRT_NO_EXTRAS = two G-buffer sets for strips too, FRT_FORCE_EXTRAS = three also for a whole-frame renderer)
-    if (r->pipeline() && (!(r->rb == 0 && r->re == r->H) || getenv("FRT_FORCE_EXTRAS")) && !getenv("FRT_NO_EXTRAS")) {
+    // strips own a third G-buffer set; a whole-frame renderer only under FRT_FLAG_THIRD_GSET (include/frt.h)
+    bool third = r->pipeline() && (!(r->rb == 0 && r->re == r->H) || (r->flags & FRT_FLAG_THIRD_GSET));
+#if FRT_EXPERIMENTS
+    if (getenv("FRT_NO_EXTRAS")) third = false;      // two sets for strips too
+#endif
+    if (third) {
         r->extras_bytes = arena_layout(r->W, r->H, r->off, true);
         HIP_TRY(hipMalloc((void**)&r->extras, r->extras_bytes));
         r->gsets = 3;
@@ -562,7 +575,17 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         // 1.97 at 3 and 5, 1.92 at 3 and 4; half a frame 1.41 uncut, 1.13 cut at 3, 1.09 at 3 and 4; a quarter 0.76 / 0.66 / 0.69; an
         // eighth 0.61 / 0.57 / 0.61. The second cut pays once the launch fills the chip several times over; a thin strip gets the first only.
         if ((size_t)r->W * (r->re - r->rb) < 800000u) r->ncuts = 1;
-        if (const char* e = getenv("FRT_CUTS")) {   // experiment knob: comma-separated ascending depths, "0" = never cut
+        // frt_render_opts.cut_depths: ascending depths (others are skipped); all zero = the choice above; first entry 0xFFFFFFFF = never cut
+        if (o && o->cut_depths[0] != 0u) {
+            r->ncuts = 0;
+            uint32_t last = 0;
+            for (int k = 0; k < kMaxCuts && o->cut_depths[0] != 0xFFFFFFFFu; ++k) {
+                const uint32_t v = o->cut_depths[k];
+                if (v >= 1u && v > last && v < 0xFFFFu) { r->cuts[r->ncuts++] = v; last = v; }
+            }
+        }
+#if FRT_EXPERIMENTS
+        if (const char* e = getenv("FRT_CUTS")) {   // comma-separated ascending depths, "0" = never cut
             r->ncuts = 0;
             uint32_t last = 0;
             for (const char* p = e; *p && r->ncuts < (uint32_t)kMaxCuts;) {
@@ -574,10 +597,11 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
                 if (*p == ',') ++p; else break;
             }
         }
-        if (const char* e = getenv("FRT_WAVEFRONT")) {      // experiment knob: the ray-level wavefront needs the cut at depth 1
+        if (const char* e = getenv("FRT_WAVEFRONT")) {      // the ray-level wavefront needs the cut at depth 1
             r->wavefront = atoi(e) != 0 && !(r->flags & FRT_FLAG_COMPACTION) && r->max_depth > 1 && r->max_depth < 31;
             if (r->wavefront) { r->ncuts = 1; r->cuts[0] = 1; }
         }
+#endif
         r->qcap_max = r->W * std::min(r->H, (r->re - r->rb) + 2u * kHaloSpatial);   // every traced pixel parks
         // Default capacity from the share of paths that reach the first cut (Cornell Box, oracle counts per pixel: 0.65 / 0.50 / 0.11
         // alive at depth 1 / 2 / 3): generous, but not the worst case — a full queue is not an error (run_segment_and_park), and
@@ -586,43 +610,46 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         const double share = c0 >= 3 ? 0.25 : (c0 == 2 ? 0.6 : 0.8);
         uint32_t cap = (uint32_t)std::min<double>(r->qcap_max, std::max(4096.0, share * r->qcap_max));
         if (o && o->queue_capacity) { cap = std::min(o->queue_capacity, r->qcap_max); r->qcap_fixed = true; }
+#if FRT_EXPERIMENTS
         if (const char* e = getenv("FRT_QUEUE_CAP")) { const long v = atol(e); if (v > 0) { cap = std::min<uint32_t>((uint32_t)v, r->qcap_max); r->qcap_fixed = true; } }
+#endif
         int rc = alloc_queues(r, cap);
         if (rc) return rc;
         HIP_TRY(hipMalloc((void**)&r->d_wf_counts, 2 * kWfCounterWords * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(r->d_wf_counts, 0, 2 * kWfCounterWords * sizeof(uint32_t), r->stream));
         HIP_TRY(hipMalloc((void**)&r->d_qcount, kQcountWords * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(r->d_qcount, 0, kQcountWords * sizeof(uint32_t), r->stream));
-        // Sweep direction of the tile rows (frt_kernels.hip: TileOrder): paid 2 % with round 1's kernels on one stream; with the quad-tree kernels
-        // it costs 1-2 % on one stream and on two (2.39 vs 2.34, 2.00 vs 1.97 ms), so tile rows run top to bottom unless FRT_TILE_ORDER=1.
+#if FRT_EXPERIMENTS
+        // Sweep direction of the tile rows (experiments/frt_experiment_kernels.hpp: TileOrder; resident pixel kernels only): FRT_TILE_ORDER=1
         if (const char* e = getenv("FRT_TILE_ORDER"); e && atoi(e) != 0) {
             HIP_TRY(hipMalloc((void**)&r->d_tiles, 2 * kTileStateWords * sizeof(uint32_t)));
             rc = init_tile_state(r);
             if (rc) return rc;
         }
+#endif
     }
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));   // wgpu zero-initialises textures and buffers
     if (r->extras) HIP_TRY(hipMemsetAsync(r->extras, 0, r->extras_bytes, r->stream));
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, C_COUNT * sizeof(unsigned long long), r->stream));
     int rc = upload_scene(r, s->b);
     if (rc) return rc;
-    {   // resident kernels: when the tree is shallow enough for their 16-entry stacks (FRT_RESIDENT=0: experiment knob, the plain kernels)
+    {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, r->device));
         r->num_cus = (uint32_t)prop.multiProcessorCount;
+#if FRT_EXPERIMENTS
+        // the experimental kernel forms (experiments/frt_experiment_kernels.hpp) and their knobs
         resident_plan(r->sv, r->res_nodes, r->res_tris);
-        // Opt-in (FRT_RESIDENT=1): measured 5 % faster than the plain kernels on one stream (2.47 vs 2.60 ms) but no better under the
-        // two-stream schedule (2.23 vs 2.20 ms): a resident workgroup owns its CU's LDS, so the two streams' kernels cannot share a CU.
-        r->resident = false;
         if (const char* e = getenv("FRT_RESIDENT")) r->resident = atoi(e) != 0 && r->res_nodes > 0 && !(r->flags & FRT_FLAG_COMPACTION);
-        if (const char* e = getenv("FRT_STREAM")) { r->stream_mode = atoi(e) != 0; if (atoi(e) > 1) r->shade_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: n > 1 = shade_min
+        if (const char* e = getenv("FRT_STREAM")) { r->stream_mode = atoi(e) != 0; if (atoi(e) > 1) r->shade_min = (uint32_t)std::min(64, atoi(e)); }   // n > 1 = shade_min
         if (const char* e = getenv("FRT_WG_PARK")) r->wg_park = atoi(e) != 0;
         if (const char* e = getenv("FRT_CONT_GRID")) r->cont_grid = std::max(0l, atol(e));
         if (const char* e = getenv("FRT_STREAM_SLICE")) r->stream_slice = (uint32_t)std::max(1, atoi(e));
-        if (const char* e = getenv("FRT_REFILL")) { r->refill = atoi(e) != 0; if (atoi(e) > 1) r->refill_min = (uint32_t)std::min(64, atoi(e)); }   // experiment knob: 0 off, 1 on, n > 1: refill when >= n lanes are free
+        if (const char* e = getenv("FRT_REFILL")) { r->refill = atoi(e) != 0; if (atoi(e) > 1) r->refill_min = (uint32_t)std::min(64, atoi(e)); }   // 0 off, 1 on, n > 1: refill when >= n lanes are free
         if ((r->refill || r->stream_mode) && !getenv("FRT_CUTS") && r->ncuts > 1) r->ncuts = 1;   // (those kernels replace the continuation launches of a single cut)
-        if (const char* e = getenv("FRT_RES_BATCH")) r->res_batch = (uint32_t)atoi(e);      // experiment knob: tiles per fetch (1, 2, 4)
-        if (const char* e = getenv("FRT_RES_TRIS")) { if (atoi(e) == 0) r->res_tris = false; }   // experiment knob: triangles from L2
+        if (const char* e = getenv("FRT_RES_BATCH")) r->res_batch = (uint32_t)atoi(e);      // tiles per fetch (1, 2, 4)
+        if (const char* e = getenv("FRT_RES_TRIS")) { if (atoi(e) == 0) r->res_tris = false; }   // triangles from L2
+#endif
         HIP_TRY(hipMalloc((void**)&r->d_work, kWorkWords * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(r->d_work, 0, kWorkWords * sizeof(uint32_t), r->stream));
     }
@@ -644,6 +671,9 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
         r->rb = o->row_begin; r->re = o->row_end;
         r->motion_halo = o->motion_halo_rows;
     }
+#if !FRT_EXPERIMENTS
+    if (r->flags & FRT_FLAG_COMPACTION) { fail(FRT_ERR_INVALID_ARG, "renderer_create: FRT_FLAG_COMPACTION selects an experimental kernel family that lives in lib/libfrt_exp.so (make experiments)"); delete r; return nullptr; }
+#endif
     if (renderer_init(r, s, o) != FRT_OK) { std::string keep = g_err; frt_renderer_destroy(r); g_err = keep; return nullptr; }
     return r;
 }
@@ -1106,6 +1136,7 @@ int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
     // queues that overflowed since the last call (paths were finished in place, nothing was lost): grow them while the GPU is idle
     uint32_t ov[2] = {0, 0};
     HIP_TRY(hipMemcpy(ov, r->d_qcount + 2 * 2 * (kMaxCuts + 1), sizeof(ov), hipMemcpyDeviceToHost));
+#if FRT_EXPERIMENTS
     if (getenv("FRT_DEBUG_QUEUES")) {   // (debug: the queue counters of the last launches, [stage][parity][segment])
         uint32_t qc[kQcountWords];
         HIP_TRY(hipMemcpy(qc, r->d_qcount, sizeof(qc), hipMemcpyDeviceToHost));
@@ -1113,6 +1144,7 @@ int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
         for (size_t i = 0; i < kQcountWords; ++i) fprintf(stderr, " %u", qc[i]);
         fprintf(stderr, "\n");
     }
+#endif
     if (ov[0] || ov[1]) {
         r->stats.queue_overflow += (uint64_t)ov[0] + ov[1];
         HIP_TRY(hipMemset(r->d_qcount + 2 * 2 * (kMaxCuts + 1), 0, sizeof(ov)));

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "..", "lib", "libfrt.so")
+# FRT_LIB: an alternative build of the library (lib/libfrt_exp.so = the experiments build of `make experiments`; A/B builds under _ab/)
+LIB_PATH = os.environ.get("FRT_LIB") or os.path.join(_HERE, "..", "lib", "libfrt.so")
 
 
 class VertexAttr(C.Structure):      # src/geometry.rs:4-10
@@ -33,7 +34,8 @@ class CameraUniform(C.Structure):   # src/camera.rs:4-15
 class RenderOpts(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("device", C.c_int32), ("stream", C.c_void_p),
                 ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("device_arena", C.c_void_p),
-                ("arena_bytes", C.c_uint64), ("flags", C.c_uint32), ("motion_halo_rows", C.c_uint32), ("queue_capacity", C.c_uint32)]
+                ("arena_bytes", C.c_uint64), ("flags", C.c_uint32), ("motion_halo_rows", C.c_uint32), ("queue_capacity", C.c_uint32),
+                ("cut_depths", C.c_uint32 * 4)]
 
 
 class Stats(C.Structure):
@@ -49,6 +51,7 @@ FLAG_TIMING = 1
 FLAG_COMPACTION = 2
 FLAG_USE_STREAM = 4
 FLAG_PIPELINE = 8
+FLAG_THIRD_GSET = 16
 FLAG_OVERLAP_POST = FLAG_PIPELINE      # round-1 name
 PHASE_GBUFFER, PHASE_TEMPORAL, PHASE_SPATIAL, PHASE_POST, PHASE_ALL = 1, 2, 4, 8, 15
 PHASE_SPATIAL_INNER, PHASE_SPATIAL_EDGE = 16, 32

@@ -6,11 +6,15 @@ from ._lib import (lib, check, FrtError, RenderOpts, Stats, CameraUniform, BUF_B
 
 class Renderer:
     def __init__(self, scene, width, height, max_depth=8, device=0, stream=None, rows=None, arena=None, arena_bytes=0, flags=0, motion_halo=0,
-                 queue_capacity=0):
+                 queue_capacity=0, cuts=None):
         """Renderer::new (renderer.rs:206). rows=(begin,end) restricts this renderer to an image strip; motion_halo = rows of
         previous-frame state kept valid beyond the strip for a moving camera (frt.dist.StripPlan(motion_halo=...))."""
         o = RenderOpts()
         o.max_depth, o.device, o.flags, o.queue_capacity = max_depth, device, flags, queue_capacity
+        if cuts is not None:        # frt_render_opts.cut_depths: [] = never cut
+            c = list(cuts)[:4] or [0xFFFFFFFF]
+            for k, v in enumerate(c):
+                o.cut_depths[k] = v
         if stream is not None:      # a caller-owned stream handle; 0 is the legacy default stream (torch's default current stream)
             o.stream = stream or None
             o.flags |= FLAG_USE_STREAM

@@ -169,6 +169,10 @@ typedef struct frt_render_opts {
     uint32_t queue_capacity;  /* slots of each continuation queue (paths parked between two launches of a traced stage); 0 -> sized from the
                                  share of paths that reach the first cut and grown by frt_renderer_stats after an overflow. Any value is
                                  safe: a path that finds its queue full is finished in place (frt_stats.queue_overflow counts them). */
+    uint32_t cut_depths[4];   /* ascending bounce depths at which the traced stages park their surviving paths in the continuation queues and resume
+                                 them, dense again, in a further launch. All zero -> the library's choice (3 and 4; renderers of
+                                 fewer than 0.8 M pixels: 3). cut_depths[0] = 0xFFFFFFFF -> never cut. Entries that are not ascending are skipped.
+                                 Pixels do not depend on it. */
 } frt_render_opts;
 #define FRT_FLAG_TIMING 1u          /* record per-stage HIP events every frame (frt_stats.ms_*) */
 #define FRT_FLAG_PIPELINE 8u        /* two-stream schedule: the G-buffer and the T-trace half of the temporal stage of the NEXT
@@ -180,8 +184,11 @@ typedef struct frt_render_opts {
                                        frt_renderer_buffer_info on their own stream call frt_renderer_fence first. */
 #define FRT_FLAG_OVERLAP_POST FRT_FLAG_PIPELINE   /* round-1 name */
 #define FRT_FLAG_USE_STREAM 4u      /* opts->stream is authoritative even when NULL (= the legacy default stream, e.g. torch's current stream) */
-#define FRT_FLAG_COMPACTION 2u      /* temporal / spatial stages through the workgroup-compacting kernels (opt-in: measured slower than
-                                       one thread per pixel on the Cornell Box, profiles/r1_v3_*; same pixels either way) */
+#define FRT_FLAG_COMPACTION 2u      /* EXPERIMENTS BUILD ONLY (lib/libfrt_exp.so, `make experiments`): temporal / spatial stages through the
+                                       workgroup-compacting kernels (measured slower, profiles/r1_v3_*). The product library rejects the flag. */
+#define FRT_FLAG_THIRD_GSET 16u     /* with FRT_FLAG_PIPELINE: a whole-frame renderer also owns the third G-buffer / motion / candidate set (60 B per
+                                       pixel outside the arena) that strip renderers own, so that the next frame's G-buffer + T-trace need not wait
+                                       for this frame's T-merge. No gain for a whole frame; lets tests drive that schedule. */
 
 /* FRT_PHASE_SPATIAL = the whole spatial stage. A strip renderer may issue it in two parts so that the halo exchange overlaps with
  * work: FRT_PHASE_SPATIAL_INNER (rows whose 10-row reuse neighbourhood lies inside the strip: needs nothing from a neighbour),

@@ -31,15 +31,14 @@ def gpu(frt):
     return frt
 
 
-@pytest.mark.parametrize("compaction", [False, True], ids=["pixel", "compaction"])
 @pytest.mark.parametrize("which,W,H,depth,frames", [("cornell", 128, 128, 8, 8), ("cornell", 128, 128, 1, 2), ("cornell", 200, 120, 8, 4),
                                                     ("cornell", 37, 19, 8, 3), ("cornell", 96, 64, 16, 3), ("restir", 160, 96, 8, 4)])
-def test_kernels_match_oracle_every_buffer(gpu, orc, which, W, H, depth, frames, compaction):
+def test_kernels_match_oracle_every_buffer(gpu, orc, which, W, H, depth, frames):
     frt = gpu
     fs = frt.scenes.create_cornell_box() if which == "cornell" else frt.scenes.create_restir_scene()
     os_ = orc.cornell() if which == "cornell" else orc.restir_scene()
     os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
-    r = frt.Renderer(fs, W, H, max_depth=depth, flags=frt.FLAG_COMPACTION if compaction else 0)
+    r = frt.Renderer(fs, W, H, max_depth=depth)
     ro = os_.renderer(W, H, depth, True, 16)
     for f in range(frames):
         cam = frt.CameraController().build_uniform(W / H, f, fs.num_lights)
@@ -240,16 +239,16 @@ def test_post_overlap_flag_gives_identical_frames(gpu, orc):
         assert s.read_buffer(7, last)[p.row_begin:p.row_end].tobytes() == want[p.row_begin:p.row_end].tobytes()
 
 
-@pytest.mark.parametrize("cuts", ["0", "3", "2,3,5,6", "1,2,3,4", "5,7", "1", "2,6", "abc", "3;5"])
-def test_every_cut_configuration_is_bit_identical(gpu, orc, monkeypatch, cuts):
+@pytest.mark.parametrize("cuts", [[], [3], [2, 3, 5, 6], [1, 2, 3, 4], [5, 7], [1], [2, 6], [5, 3], [3, 3, 9], [70000, 2]])
+def test_every_cut_configuration_is_bit_identical(gpu, orc, cuts):
     """The continuation-queue protocol (pixel kernel -> park after the roulette -> continue kernels, one counter per segment) must
-    not depend on where or how often paths are cut. FRT_CUTS is the experiment knob frt_renderer_create reads."""
+    not depend on where or how often paths are cut: frt_render_opts.cut_depths ([] = never cut; lists that are not ascending or hold
+    out-of-range depths are reduced to their ascending valid entries and must not change pixels either)."""
     frt = gpu
-    monkeypatch.setenv("FRT_CUTS", cuts)      # ("abc", "3;5": malformed lists must neither hang the parser nor change pixels)
     W, H, depth = 160, 96, 8
     fs = frt.scenes.create_cornell_box()
     os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
-    r = frt.Renderer(fs, W, H, max_depth=depth)
+    r = frt.Renderer(fs, W, H, max_depth=depth, cuts=cuts)
     ro = os_.renderer(W, H, depth, True, 16)
     for f in range(4):
         cam = frt.CameraController().build_uniform(W / H, f, 2)
@@ -257,24 +256,6 @@ def test_every_cut_configuration_is_bit_identical(gpu, orc, monkeypatch, cuts):
         compare_all(r.read_buffer, ro.read, f, f"cuts {cuts}")
     st, so = r.stats(), ro.stats()["total"]
     assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
-
-
-@pytest.mark.parametrize("flags", [0, 8])
-def test_sweep_direction_is_scheduling_only(gpu, orc, monkeypatch, flags):
-    """FRT_TILE_ORDER=1 (opt-in since the quad-tree kernels): the traced pixel kernels sweep the tile rows from the expensive end of the image,
-    the direction fed back by the last workgroup of each launch. Which pixels a workgroup computes, never what: every buffer equals the oracle,
-    also while the direction flips between frames."""
-    frt = gpu
-    monkeypatch.setenv("FRT_TILE_ORDER", "1")
-    W, H = 192, 160
-    fs = frt.scenes.create_cornell_box()
-    os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
-    r = frt.Renderer(fs, W, H, flags=flags)
-    ro = os_.renderer(W, H, 8, True, 16)
-    for f in range(5):
-        cam = frt.CameraController().build_uniform(W / H, f, 2)
-        r.render(cam); ro.render(cam)
-        compare_all(r.read_buffer, ro.read, f, f"tile order, flags {flags}")
 
 
 def test_moving_camera_strips_equal_whole_image(gpu):
@@ -356,18 +337,19 @@ def test_config2_4k_eight_strips_equal_whole(gpu):
 
 
 @pytest.mark.parametrize("three_sets", [False, True], ids=["two-sets", "three-sets"])
-def test_pipeline_speculation_is_adopted_for_a_static_camera_and_dropped_for_a_moving_one(gpu, orc, monkeypatch, three_sets):
+def test_pipeline_speculation_is_adopted_for_a_static_camera_and_dropped_for_a_moving_one(gpu, orc, three_sets):
     """FRT_FLAG_PIPELINE: G-buffer + T-trace of frame f+1 run ahead under a speculated camera. Static camera: adopted from the third
     frame on (one frame to see the camera, one to see that it did not move), every buffer and the ray counts identical to the oracle.
     Moving camera: never speculated (nothing to drop). A camera that stops / starts moving: wrong guesses are dropped, same pixels."""
     frt = gpu
     import _scenes
-    if three_sets:      # what strip renderers get: a third G-buffer set, the ahead stream ordered behind the PREVIOUS frame's T-merge; here on a
-        monkeypatch.setenv("FRT_FORCE_EXTRAS", "1")     # whole frame, so that frames enqueued back to back can be compared with the oracle
+    # three sets: what strip renderers get — a third G-buffer set, the ahead stream ordered behind the PREVIOUS frame's T-merge; here on a
+    # whole frame (FRT_FLAG_THIRD_GSET), so that frames enqueued back to back can be compared with the oracle
+    pipe = frt.FLAG_PIPELINE | (frt.FLAG_THIRD_GSET if three_sets else 0)
     W, H, N = 160, 96, 7
     fs = frt.scenes.create_cornell_box()
     os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
-    r = frt.Renderer(fs, W, H, flags=frt.FLAG_PIPELINE); ro = os_.renderer(W, H, 8, True, 16)
+    r = frt.Renderer(fs, W, H, flags=pipe); ro = os_.renderer(W, H, 8, True, 16)
     for f in range(N):
         cam = frt.CameraController().build_uniform(W / H, f, 2)
         r.render(cam); ro.render(cam)
@@ -376,7 +358,7 @@ def test_pipeline_speculation_is_adopted_for_a_static_camera_and_dropped_for_a_m
     assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
     assert st["speculated_frames"] == N - 2 and st["discarded_speculations"] == 0, st
     # static -> moving -> static: the guess made during the last static frame is wrong and must be dropped
-    r = frt.Renderer(fs, W, H, flags=frt.FLAG_PIPELINE); ro = os_.renderer(W, H, 8, True, 16)
+    r = frt.Renderer(fs, W, H, flags=pipe); ro = os_.renderer(W, H, 8, True, 16)
     moving = _scenes.moving_camera_uniforms(frt, W / H, 2, 12)
     seq = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(4)] + moving[4:8]
     still = moving[7]
@@ -388,10 +370,10 @@ def test_pipeline_speculation_is_adopted_for_a_static_camera_and_dropped_for_a_m
             compare_all(r.read_buffer, ro.read, f, "pipeline, camera starts and stops moving")
     st, so = r.stats(), ro.stats()["total"]
     assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
-    assert st["discarded_speculations"] in (1, 2) and st["speculated_frames"] >= 3, st     # (one guess per frame run ahead: FRT_SPEC_DEPTH)
+    assert st["discarded_speculations"] in (1, 2) and st["speculated_frames"] >= 3, st     # (one guess per frame run ahead)
 
 
-def test_three_gbuffer_sets_at_full_size_equal_two(gpu, monkeypatch):
+def test_three_gbuffer_sets_at_full_size_equal_two(gpu):
     """1920x1080, 16 frames enqueued back to back: a renderer with a third G-buffer set (ahead stream a whole frame ahead of the chain,
     what strips run) against the default two sets: accumulation, both reservoir buffers, G-buffer and ray counts identical."""
     frt = gpu
@@ -399,9 +381,7 @@ def test_three_gbuffer_sets_at_full_size_equal_two(gpu, monkeypatch):
     fs = frt.scenes.create_cornell_box()
     cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(N)]
     a = frt.Renderer(fs, W, H, flags=frt.FLAG_PIPELINE)
-    monkeypatch.setenv("FRT_FORCE_EXTRAS", "1")
-    b = frt.Renderer(fs, W, H, flags=frt.FLAG_PIPELINE)
-    monkeypatch.delenv("FRT_FORCE_EXTRAS")
+    b = frt.Renderer(fs, W, H, flags=frt.FLAG_PIPELINE | frt.FLAG_THIRD_GSET)
     for c in cams:
         a.render(c); b.render(c)
     last = (N - 1) % 2
@@ -452,11 +432,7 @@ def test_queue_overflow_finishes_paths_in_place(gpu, orc):
     os_ = orc.cornell(); os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
     for flags in (0, frt.FLAG_PIPELINE):
         ro = os_.renderer(W, H, 8, True, 16)
-        os.environ["FRT_CUTS"] = "2,4"       # (a small image would run uncut by default)
-        try:
-            r = frt.Renderer(fs, W, H, flags=flags, queue_capacity=100)
-        finally:
-            os.environ.pop("FRT_CUTS")
+        r = frt.Renderer(fs, W, H, flags=flags, queue_capacity=100, cuts=[2, 4])       # (a small image would be cut once, at 3, by default)
         for f in range(4):
             cam = frt.CameraController().build_uniform(W / H, f, 2)
             r.render(cam); ro.render(cam)

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the knobs below are read by the EXPERIMENTS build only: make -C fast-raytracing-wgpu_amd experiments)
+export FRT_LIB=${FRT_LIB:-$(pwd)/fast-raytracing-wgpu_amd/lib/libfrt_exp.so}
 # experiment: bounce kernel with lane refill (FRT_REFILL) at several cut depths, vs the continuation launches
 export FRT_RESIDENT=0
 FRT_REFILL=1 timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "every_cut or kernels_match" 2>&1 | tail -3

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the knobs below are read by the EXPERIMENTS build only: make -C fast-raytracing-wgpu_amd experiments)
+export FRT_LIB=${FRT_LIB:-$(pwd)/fast-raytracing-wgpu_amd/lib/libfrt_exp.so}
 # experiment: resident kernels (BVH in LDS) vs plain, one stream (FRT_FLAGS=1) and two streams (9)
 for fl in 1 9; do
   echo "== flags $fl"

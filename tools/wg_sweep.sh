@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the knobs below are read by the EXPERIMENTS build only: make -C fast-raytracing-wgpu_amd experiments)
+export FRT_LIB=${FRT_LIB:-$(pwd)/fast-raytracing-wgpu_amd/lib/libfrt_exp.so}
 for fl in 1 9; do
   echo "== flags $fl"
   FRT_FLAGS=$fl FRT_RESIDENT=0 python3 tools/frame_time.py 2>&1 | tail -1
