@@ -83,9 +83,10 @@ static float rnd() { g_rng = g_rng * 747796405u + 2891336453u; uint32_t w = ((g_
 template <class T> static T* upload(const std::vector<T>& v) { T* d = nullptr; CHECK(hipMalloc((void**)&d, std::max<size_t>(v.size() * sizeof(T), 16))); CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return d; }
 
 static QQuadView g_qv;
+static uint32_t g_per_thread = 2;
 template <int VARIANT>
 static double run(const char* name, const SceneView& sv, const RayRec* d_sh, const RayRec* d_cl, uint32_t n, Out* d_out, Out& res) {
-    const uint32_t per_thread = 2;
+    const uint32_t per_thread = g_per_thread;
     const uint32_t grid = (n + 256u * per_thread - 1u) / (256u * per_thread);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -149,7 +150,8 @@ int main(int argc, char** argv) {
         g_qv.qmin = mk3(b.qmin[0], b.qmin[1], b.qmin[2]); g_qv.qstep = mk3(b.qstep[0], b.qstep[1], b.qstep[2]);
     }
     // rays: tiles of 64 with a common base point
-    const uint32_t n = 1u << 23;
+    // argv[3]: log2 of the ray pairs (default 23: ~16 rounds of workgroups, the throughput regime; 18 = ONE round: the latency regime of a thin image strip)
+    const uint32_t n = 1u << (argc > 3 ? atoi(argv[3]) : 23);
     std::vector<double> cum(b.tris.size());
     double acc = 0.0;
     auto crossv = [](const float* a, const float* c, float* o) { o[0] = a[1] * c[2] - a[2] * c[1]; o[1] = a[2] * c[0] - a[0] * c[2]; o[2] = a[0] * c[1] - a[1] * c[0]; };
@@ -194,6 +196,7 @@ int main(int argc, char** argv) {
     Out* d_out; CHECK(hipMalloc((void**)&d_out, sizeof(Out) * (size_t)(n / 64 + 1024)));
     Out r0{}, r{};
     const int only = argc > 2 ? atoi(argv[2]) : -1;
+    if (argc > 4) g_per_thread = (uint32_t)atoi(argv[4]);
     run<0>("seq", sv, d_sh, d_cl, n, d_out, r0);
     auto same = [&](const Out& x) { return x.occluded == r0.occluded && x.hits == r0.hits && x.tri_sum == r0.tri_sum && x.t_sum == r0.t_sum; };
     bool ok = true;
