@@ -12,6 +12,9 @@
 namespace frt {
 
 static constexpr int kBlock = 256;
+#ifndef FRT_WAVES
+#define FRT_WAVES 4      // waves per SIMD the traced kernels are built for (A/B builds: 5 needs <= 96 VGPRs and <= 32 KiB of LDS per workgroup)
+#endif
 
 __device__ __forceinline__ bool tile_pixel_at(const FrameView& fv, uint32_t tx, uint32_t ty, uint32_t& px, uint32_t& py) {
     uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
@@ -122,7 +125,7 @@ __device__ __forceinline__ bool run_segment_and_park(Ctx& c, LoopState& s, uint3
 }
 
 template <int STAGE>
-__global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, uint32_t* zero_counts, bool wg_park) {
+__global__ void __launch_bounds__(kBlock, FRT_WAVES) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, uint32_t* zero_counts, bool wg_park) {
     constexpr int THREADS = kBlock;
     __shared__ uint32_t s_stack[kStackDepth * THREADS];
     __shared__ uint32_t s_cnt[2];
@@ -173,7 +176,7 @@ __global__ void __launch_bounds__(kBlock, 4) pixel_kernel(SceneView sc, FrameVie
 
 // Resumes parked paths for bounces [d0, d1); survivors are parked again in `qout` (d1 < MAX_DEPTH) or finished here.
 template <int STAGE>
-__global__ void __launch_bounds__(kBlock, 4) continue_kernel(SceneView sc, FrameView fv, ContQueue qin, ContQueue qout, uint32_t d0, uint32_t d1) {
+__global__ void __launch_bounds__(kBlock, FRT_WAVES) continue_kernel(SceneView sc, FrameView fv, ContQueue qin, ContQueue qout, uint32_t d0, uint32_t d1) {
     constexpr int THREADS = kBlock;
     __shared__ uint32_t s_stack[kStackDepth * THREADS];
     __shared__ uint32_t s_cnt[2];

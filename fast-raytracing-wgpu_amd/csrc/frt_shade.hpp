@@ -473,7 +473,11 @@ FRT_HD void post_pixel_t(const FrameView& fv, uint32_t px, uint32_t py, const Ta
             if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
             const TapData t = taps.get(nx, ny);
             float w_spatial = gauss(length2(mk2((float)dx, (float)dy)), 1.5f);
-            float w_color = gauss(length(t.albedo - center_albedo), 0.2f);
+            // equal albedo (every tap on a surface of one material: most of them): gauss(length(0)) = exp2(-0) = 1 exactly (frt_math.hpp: the
+            // polynomial of exp2f_ at -0 is 1), so the square root and the exponential are skipped — by the whole wave when all its lanes agree
+            const f3 d_albedo = t.albedo - center_albedo;
+            float w_color = 1.0f;
+            if (!(d_albedo.x == 0.0f && d_albedo.y == 0.0f && d_albedo.z == 0.0f)) w_color = gauss(length(d_albedo), 0.2f);
             float dot_normal = clampf(dot(center_normal, t.normal), 0.0f, 1.0f);
             float w_normal = pow20_(dot_normal);
             float w_pos = gauss(length(t.pos - center_pos), 0.1f);

@@ -13,7 +13,10 @@
 
 namespace frt {
 
-static const int kStackDepth = 32;
+#ifndef FRT_STACK
+#define FRT_STACK 32      // (A/B builds only: a shallower LDS stack for scenes whose quad tree needs no more)
+#endif
+static const int kStackDepth = FRT_STACK;
 
 struct InstanceView { uint32_t mesh_id, mat_id, first_tri, flip; float w2o[9]; float pad[3]; };   // = InstanceDev (64 B)
 struct MeshInfoView { uint32_t vertex_offset, index_offset, pad0, pad1; };
