@@ -192,6 +192,32 @@ int main(int argc, char** argv) {
             sh[i] = RayRec{o[0], o[1], o[2], dl * 0.999f, dd[0] / dl, dd[1] / dl, dd[2] / dl, 0.001f};
         }
     }
+    // argv[5]: ray order. 0 = tiles (above). 1 = "queue order": the pairs shuffled, every lane of a wave from a different tile (what a continuation
+    // launch sees: parked paths in arrival order). 2 = shuffled, then binned by the direction octant of the closest-hit ray and a 2x2x2 cell of its
+    // origin (64 bins, stable). 3 = binned by octant only.
+    const int order = argc > 5 ? atoi(argv[5]) : 0;
+    if (order > 0) {
+        std::vector<uint32_t> perm(n);
+        for (uint32_t i = 0; i < n; ++i) perm[i] = i;
+        for (uint32_t i = n - 1; i > 0; --i) { const uint32_t j = (uint32_t)(rnd() * (float)(i + 1)) % (i + 1); std::swap(perm[i], perm[j]); }
+        if (order >= 2) {
+            auto key = [&](uint32_t i) {
+                const RayRec& r = cl[i];
+                uint32_t k = (r.dx < 0 ? 1u : 0u) | (r.dy < 0 ? 2u : 0u) | (r.dz < 0 ? 4u : 0u);
+                if (order == 2) k |= ((r.ox > 0 ? 1u : 0u) | (r.oy > 0 ? 2u : 0u) | (r.oz > 0 ? 4u : 0u)) << 3;
+                // 4: 2x2x2 origin cell only; 5: 4x4x4 cells only; 6: 4x4x4 cells + octant (scene box [-1, 1]^3)
+                auto c4 = [](float v) { int c = (int)((v + 1.0f) * 2.0f); return (uint32_t)(c < 0 ? 0 : (c > 3 ? 3 : c)); };
+                if (order == 4) k = (r.ox > 0 ? 1u : 0u) | (r.oy > 0 ? 2u : 0u) | (r.oz > 0 ? 4u : 0u);
+                if (order == 5) k = c4(r.ox) | (c4(r.oy) << 2) | (c4(r.oz) << 4);
+                if (order == 6) k |= (c4(r.ox) | (c4(r.oy) << 2) | (c4(r.oz) << 4)) << 3;
+                return k;
+            };
+            std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b2) { return key(a) < key(b2); });
+        }
+        std::vector<RayRec> sh2(n), cl2(n);
+        for (uint32_t i = 0; i < n; ++i) { sh2[i] = sh[perm[i]]; cl2[i] = cl[perm[i]]; }
+        sh.swap(sh2); cl.swap(cl2);
+    }
     RayRec* d_sh = upload(sh); RayRec* d_cl = upload(cl);
     Out* d_out; CHECK(hipMalloc((void**)&d_out, sizeof(Out) * (size_t)(n / 64 + 1024)));
     Out r0{}, r{};

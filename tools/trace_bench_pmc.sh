@@ -12,6 +12,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_tb/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import sys
 rays = 2 * (1 << 23)
 print(f"{'kernel':28s} {'VALU/ray-lane':>13s} {'wave-instr':>11s} {'lane_util':>9s} {'SALU/VALU':>9s} {'VMEM_RD':>10s} {'wave_cyc/VALU':>13s} {'busy_cyc':>10s}")
 for k, v in sorted(agg.items()):
