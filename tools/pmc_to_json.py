@@ -2,7 +2,7 @@
 into the JSON bench.py reads for its roofline block: per-kernel per-launch means, HBM bytes and VALU wave-instructions per frame, the
 calibrated issue cost, and the hash of the kernel sources they were measured on (bench.py withholds the numbers when the hash differs).
 Run HERE (the repository with .git), after the gpurun call that produced the passes:
-    python tools/pmc_to_json.py r2 > profiles/r2_pmc.json"""
+    python tools/pmc_to_json.py r3 > profiles/r3_pmc.json"""
 import collections, csv, glob, json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -38,6 +38,33 @@ for k, v in tab.items():
     if "SQ_WAIT_ANY" in v and v.get("SQ_WAVE_CYCLES"):
         e["wait_frac"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
     kern[k] = e
+# the per-CU load path of the one-stream frame (tools/pmc_ta.sh <tag>ta): vector L1 (TCP) hit rate, texture addresser / data return busy
+l1 = {}
+ta = collections.defaultdict(dict)
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}ta_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            if "frt::" in k:
+                name = k.replace("frt::", "").split("(")[0].replace("void ", "")
+                for c, x in v.items():
+                    ta[name][c] = sum(x) / len(x)
+for k, v in ta.items():
+    e = {}
+    if v.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        e["l1_hit_rate"] = 1.0 - v.get("TCP_TCC_READ_REQ_sum", 0.0) / v["TCP_TOTAL_CACHE_ACCESSES_sum"]
+        if v.get("TCP_TCC_READ_REQ_sum"):
+            e["l1_miss_latency_cycles"] = v.get("TCP_TCC_READ_REQ_LATENCY_sum", 0.0) / v["TCP_TCC_READ_REQ_sum"]
+    if v.get("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; TA_BUSY_avr is a per-TA average; TD_TD_BUSY_sum sums 256 CUs
+        e["ta_busy_frac"] = v.get("TA_BUSY_avr", 0.0) / (v["GRBM_GUI_ACTIVE"] / 8.0)
+        e["td_busy_frac"] = v.get("TD_TD_BUSY_sum", 0.0) / 256.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
+    if e:
+        l1[k] = {kk: round(vv, 4) for kk, vv in e.items()}
 calib = {}
 try:
     for line in open(os.path.join(ROOT, "gpurun_out", "valu_calib.txt")):
@@ -50,7 +77,7 @@ sat = calib.get("independent_K8") or calib.get("independent_K4") or {"simd_cycle
 out = {
     "source_hash": source_hash(),
     "git_head": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
-    "workload": "bench.py --cpu-frames 0 --steps 16 --warmup 4 (1920x1080, two-stream schedule), per-launch means",
+    "workload": "bench.py --cpu-frames 0 --no-4k --steps 16 --warmup 4 (1920x1080, two-stream schedule), per-launch means",
     "kernels": kern,
     "hbm_bytes_per_frame": sum(e.get("hbm_bytes", 0) * e["launches_per_frame"] for e in kern.values()),
     "valu_insts_per_frame": sum(e.get("SQ_INSTS_VALU", 0) * e["launches_per_frame"] for e in kern.values()),
@@ -59,5 +86,6 @@ out = {
     "shader_clock_ghz": sat["shader_clock_ghz"],
     "simds": 1024,
     "calibration": calib,
+    "l1": l1,
 }
 print(json.dumps(out, indent=1))
