@@ -256,7 +256,7 @@ static void build_quad_nodes(SceneBuilder& b) {
         b.quad_nodes[h] = q;
     }
     b.quad_stack_need = need[0];
-    if (b.quad_stack_need > (uint32_t)kStackDepth) b.error = "quad tree exceeds the traversal stack";   // (cannot happen: see above)
+    if (b.quad_stack_need > (uint32_t)kStackDepth - 1u) b.error = "quad tree exceeds the traversal stack";   // (cannot happen: see above; the last row of the LDS array is not a stack entry, frt_kernels.hip: kMiscRow)
 }
 
 void SceneBuilder::build_gpu_layout() {

@@ -12,6 +12,11 @@
 namespace frt {
 
 static constexpr int kBlock = 256;
+// LDS of a traced workgroup = the stack array and nothing else: exactly 32 KiB, five workgroups per CU by LDS. The quad tree of any scene the
+// builder accepts needs at most kStackDepth - 1 entries per lane (frt_bvh.cpp: build_quad_nodes folds only within that budget; a plain binary
+// subtree is at most kMaxBvhDepth = 30 deep), so the LAST row of the array is never a stack entry: the workgroup's few shared words (ray-count
+// partial sums, the queue reservation scratch) live there.
+static constexpr int kMiscRow = kStackDepth - 1;
 #ifndef FRT_WAVES
 #define FRT_WAVES 4      // waves per SIMD the traced kernels are built for (A/B builds: 5 needs <= 96 VGPRs and <= 32 KiB of LDS per workgroup)
 #endif
@@ -41,7 +46,7 @@ __device__ __forceinline__ void flush_ray_counters(const FrameView& fv, uint32_t
 // G-buffer: one primary ray per pixel, coherent within the 8x8 tile (lane utilisation 96 %): plain thread-per-pixel launch.
 __global__ void __launch_bounds__(kBlock) gbuffer_kernel(SceneView sc, FrameView fv) {
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
-    __shared__ uint32_t s_cnt[2];
+    uint32_t* const s_cnt = &s_stack[kMiscRow * kBlock];
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t px, py;
@@ -128,8 +133,8 @@ template <int STAGE>
 __global__ void __launch_bounds__(kBlock, FRT_WAVES) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, uint32_t* zero_counts, bool wg_park) {
     constexpr int THREADS = kBlock;
     __shared__ uint32_t s_stack[kStackDepth * THREADS];
-    __shared__ uint32_t s_cnt[2];
-    __shared__ uint32_t s_tmp[8];
+    uint32_t* const s_cnt = &s_stack[kMiscRow * THREADS];
+    uint32_t* const s_tmp = s_cnt + 8;
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
@@ -179,7 +184,7 @@ template <int STAGE>
 __global__ void __launch_bounds__(kBlock, FRT_WAVES) continue_kernel(SceneView sc, FrameView fv, ContQueue qin, ContQueue qout, uint32_t d0, uint32_t d1) {
     constexpr int THREADS = kBlock;
     __shared__ uint32_t s_stack[kStackDepth * THREADS];
-    __shared__ uint32_t s_cnt[2];
+    uint32_t* const s_cnt = &s_stack[kMiscRow * THREADS];
     const uint32_t filled = *qin.count;
     const uint32_t n = filled < qin.capacity ? filled : qin.capacity;
     if (blockIdx.x * (uint32_t)THREADS >= n) return;   // uniform per workgroup
