@@ -376,13 +376,15 @@ FRT_HD void path_loop_split(Ctx& c, LoopState& s, uint32_t depth_begin, uint32_t
 
 // ---- continuation records: a LoopState parked in HBM between two launches -------------------------------------------------
 // SoA over slots: word k of slot i lives at words[k * capacity + i], so a wave parking / fetching consecutive slots moves full
-// 256-byte rows per word. 22 words (88 B) per path; the spatial stage adds its merged reservoir (8 words).
+// 256-byte rows per word. 22 words (88 B) per path; the spatial stage adds what its finalisation reads of the merged reservoir: y (the seed being
+// re-traced), w_sum and M — spatial_finalize (frt_path.hpp, restir_spatial.wgsl:996-1015) overwrites W, s_path and p_hat, so those five words neither
+// travel through the queue nor stay live in registers across the bounces.
 // `count` may run past `capacity`: a path that finds the queue full is finished in place by the lane that holds it (never dropped) and
 // counted in `overflow`; readers use min(*count, capacity) slots.
 // nsub > 1: the queue is cut into nsub regions of capacity / nsub slots, each with its own counter (count[0 .. nsub)): tens of thousands of
 // atomics on ONE address cost ~13 ns each on this chip (measured: 8,192 waves taking one ticket each = 120 us), eight addresses run side by side.
 struct ContQueue { uint32_t* words; uint32_t* count; uint32_t capacity; uint32_t* overflow; uint32_t nsub; };
-static constexpr int kContWordsPath = 22, kContWordsSpatial = 30;
+static constexpr int kContWordsPath = 22, kContWordsSpatial = 25;
 
 FRT_HD void cont_store(const ContQueue& q, uint32_t slot, uint32_t pix, uint32_t rng, bool owned, const LoopState& s, const ReservoirView* r) {
     uint32_t* w = q.words + slot;
@@ -394,10 +396,7 @@ FRT_HD void cont_store(const ContQueue& q, uint32_t slot, uint32_t pix, uint32_t
                          s.v1_pos.x, s.v1_pos.y, s.v1_pos.z, s.last_bsdf_pdf};
 #pragma unroll
     for (int k = 0; k < 19; ++k) w[(size_t)(3 + k) * cap] = f2u(f[k]);
-    if (r) {
-        w[22 * cap] = r->y; w[23 * cap] = f2u(r->w_sum); w[24 * cap] = r->M; w[25 * cap] = f2u(r->W);
-        w[26 * cap] = f2u(r->sx); w[27 * cap] = f2u(r->sy); w[28 * cap] = f2u(r->sz); w[29 * cap] = f2u(r->p_hat);
-    }
+    if (r) { w[22 * cap] = r->y; w[23 * cap] = f2u(r->w_sum); w[24 * cap] = r->M; }
 }
 FRT_HD void cont_load(const ContQueue& q, uint32_t slot, uint32_t& pix, uint32_t& rng, bool& owned, LoopState& s, ReservoirView* r) {
     const uint32_t* w = q.words + slot;
@@ -412,10 +411,7 @@ FRT_HD void cont_load(const ContQueue& q, uint32_t slot, uint32_t& pix, uint32_t
     s.accumulated = mk3(f[9], f[10], f[11]); s.next_dir = mk3(f[12], f[13], f[14]); s.v1_pos = mk3(f[15], f[16], f[17]);
     s.last_bsdf_pdf = f[18];
     s.alive = true;
-    if (r) {
-        r->y = w[22 * cap]; r->w_sum = u2f(w[23 * cap]); r->M = w[24 * cap]; r->W = u2f(w[25 * cap]);
-        r->sx = u2f(w[26 * cap]); r->sy = u2f(w[27 * cap]); r->sz = u2f(w[28 * cap]); r->p_hat = u2f(w[29 * cap]);
-    }
+    if (r) { r->y = w[22 * cap]; r->w_sum = u2f(w[23 * cap]); r->M = w[24 * cap]; r->W = 0.0f; r->sx = r->sy = r->sz = 0.0f; r->p_hat = 0.0f; }
 }
 
 struct PathOut { f3 radiance; f3 v1_pos; };
