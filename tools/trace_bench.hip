@@ -57,6 +57,10 @@ __global__ void __launch_bounds__(256, 4) bench_kernel(SceneView sc, QQuadView q
             trace4_q16<true>(sc, qv, mk3(a.ox, a.oy, a.oz), mk3(a.dx, a.dy, a.dz), a.tmin, a.tmax, stk, 256u, ha);
             occluded = ha.tri != 0xFFFFFFFFu;
             trace4_q16<false>(sc, qv, mk3(b.ox, b.oy, b.oz), mk3(b.dx, b.dy, b.dz), b.tmin, b.tmax, stk, 256u, hb);
+        } else if (VARIANT == 6) {
+            trace4_postpone<true>(sc, mk3(a.ox, a.oy, a.oz), mk3(a.dx, a.dy, a.dz), a.tmin, a.tmax, stk, 256u, ha);
+            occluded = ha.tri != 0xFFFFFFFFu;
+            trace4_postpone<false>(sc, mk3(b.ox, b.oy, b.oz), mk3(b.dx, b.dy, b.dz), b.tmin, b.tmax, stk, 256u, hb);
         } else if (VARIANT == 4) {
             trace4_xload<true>(sc, mk3(a.ox, a.oy, a.oz), mk3(a.dx, a.dy, a.dz), a.tmin, a.tmax, stk, 256u, ha);
             occluded = ha.tri != 0xFFFFFFFFu;
@@ -231,6 +235,7 @@ int main(int argc, char** argv) {
     if (only < 0 || only == 3) { run<3>("pair3", sv, d_sh, d_cl, n, d_out, r); ok &= same(r); }
     if (only < 0 || only == 4) { run<4>("early+4ld", sv, d_sh, d_cl, n, d_out, r); }
     if (only < 0 || only == 5) { run<5>("q16 4ld", sv, d_sh, d_cl, n, d_out, r); ok &= same(r); }
+    if (only < 0 || only == 6) { run<6>("postpone", sv, d_sh, d_cl, n, d_out, r); ok &= same(r); }
     printf(ok ? "checksums equal\n" : "CHECKSUM MISMATCH\n");
     return ok ? 0 : 2;
 }
