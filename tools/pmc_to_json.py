@@ -68,6 +68,8 @@ for k, v in ta.items():
 calib = {}
 try:
     for line in open(os.path.join(ROOT, "gpurun_out", "valu_calib.txt")):
+        if line.startswith("["):      # (the half-wave runs of tools/valu_calib.hip: not the calibration)
+            continue
         m = re.search(r"(independent|dependent)\s+K=(\d).*shader clock ([\d.]+) GHz.*a wave needs ([\d.]+) cycles.*-> ([\d.]+) SIMD cycles", line)
         if m:
             calib[f"{m.group(1)}_K{m.group(2)}"] = {"shader_clock_ghz": float(m.group(3)), "own_cycles_per_inst": float(m.group(4)), "simd_cycles_per_wave_inst": float(m.group(5))}
