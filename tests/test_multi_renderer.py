@@ -97,3 +97,17 @@ def test_multi_reset_and_errors(gpu):
         frt.MultiRenderer(scene, W, H, [0, 99])          # device ordinal out of range
     with pytest.raises(frt.FrtError):
         frt.MultiRenderer(scene, 64, 40, [0] * 8)       # strips thinner than the halo
+
+
+def test_bench_native_rehearsal_on_one_gpu(gpu):
+    """`bench.py --gpus 3 --native`: ONE process, three strip renderers through frt_multi_renderer (all on this box's one GPU), one JSON line."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FRT_BENCH_ONE_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--native", "--steps", "6", "--warmup", "2", "--no-4k"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 3 and res["config"]["native"] and res["value"] > 0
+    assert 17.0e6 < res["config"]["rays_per_frame"] < 18.5e6          # the same frame as one renderer traces (17.76 M rays)
