@@ -200,7 +200,7 @@ int main(int argc, char** argv) {
     // launch sees: parked paths in arrival order). 2 = shuffled, then binned by the direction octant of the closest-hit ray and a 2x2x2 cell of its
     // origin (64 bins, stable). 3 = binned by octant only.
     const int order = argc > 5 ? atoi(argv[5]) : 0;
-    if (order > 0) {
+    if (order > 0 && order < 7) {
         std::vector<uint32_t> perm(n);
         for (uint32_t i = 0; i < n; ++i) perm[i] = i;
         for (uint32_t i = n - 1; i > 0; --i) { const uint32_t j = (uint32_t)(rnd() * (float)(i + 1)) % (i + 1); std::swap(perm[i], perm[j]); }
@@ -221,6 +221,20 @@ int main(int argc, char** argv) {
         std::vector<RayRec> sh2(n), cl2(n);
         for (uint32_t i = 0; i < n; ++i) { sh2[i] = sh[perm[i]]; cl2[i] = cl[perm[i]]; }
         sh.swap(sh2); cl.swap(cl2);
+    }
+    // 7 / 8: tile order kept, but inside every block of 256 (7) or 64 (8) consecutive pairs — a workgroup's / a wave's rays — the pairs are sorted by
+    // the direction octant of the closest-hit ray: what exchanging rays between the lanes of a workgroup before a bounce could buy
+    if (order == 7 || order == 8) {
+        const uint32_t blk = order == 7 ? 256u : 64u;
+        auto oct = [&](const RayRec& r) { return (r.dx < 0 ? 1u : 0u) | (r.dy < 0 ? 2u : 0u) | (r.dz < 0 ? 4u : 0u); };
+        for (uint32_t b0 = 0; b0 + blk <= n; b0 += blk) {
+            std::vector<uint32_t> idx(blk);
+            for (uint32_t i = 0; i < blk; ++i) idx[i] = b0 + i;
+            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b2) { return oct(cl[a]) < oct(cl[b2]); });
+            std::vector<RayRec> s2(blk), c2(blk);
+            for (uint32_t i = 0; i < blk; ++i) { s2[i] = sh[idx[i]]; c2[i] = cl[idx[i]]; }
+            std::copy(s2.begin(), s2.end(), sh.begin() + b0); std::copy(c2.begin(), c2.end(), cl.begin() + b0);
+        }
     }
     RayRec* d_sh = upload(sh); RayRec* d_cl = upload(cl);
     Out* d_out; CHECK(hipMalloc((void**)&d_out, sizeof(Out) * (size_t)(n / 64 + 1024)));
