@@ -13,12 +13,22 @@
 //   rows and (b) an event of the destination's own main stream that lies behind the last reader of the halo rows it overwrites;
 //   the consumer stream (main stream, or the edge stream for "mid") then waits for the copy's event.
 // Reads gather the strips' rows. Images are bit-identical to a single renderer's (tests: every logical device mapped to ordinal 0).
+// Host side: ONE WORKER THREAD PER STRIP enqueues that strip's launches, copies and event operations (about 85 us of host time per strip and
+// frame: eight strips from one thread would take 0.68 ms per frame against the 0.36 ms a 1/8 strip of a 1080p frame needs on its GPU —
+// tools/host_enqueue.py). A frame is two steps with a host barrier between them, so that every event is recorded before a neighbour's
+// thread makes a stream wait for it (hipStreamWaitEvent on an event that has not been recorded yet would not wait at all):
+//   step A  incoming "post" / "pre" copies (their source events were recorded in the previous frame) | G-buffer + T-trace + T-merge | record ev_tm
+//   step B  incoming "mid" copies | spatial interior | edge stream waits for the copies | spatial edge + continuations | post | records | end of frame
+// frt_multi_renderer_render returns when every strip's frame is ENQUEUED (the GPUs run behind, as with frt_renderer_render).
 #include "frt_scene.hpp"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace frt { int set_error(int code, const std::string& msg); }
@@ -40,6 +50,10 @@ struct Strip {
     hipStream_t copy = nullptr;                       // this strip's incoming halo rows
     hipEvent_t ev_tm = nullptr, ev_spatial = nullptr, ev_post = nullptr;      // recorded on the main stream behind T-merge / spatial / post of the current frame
     hipEvent_t ev_copy_pre = nullptr, ev_copy_mid = nullptr, ev_copy_post = nullptr;
+    void* p_res[2] = {nullptr, nullptr};              // device addresses of reservoir_buffers[0 / 1] and accumulation[0 / 1]: fixed for the renderer's life, so a
+    void* p_acc[2] = {nullptr, nullptr};              // neighbour's worker thread reads them here instead of through the renderer handle
+    std::thread worker;
+    int status = FRT_OK; std::string message;         // of the last step this strip's worker ran
 };
 
 struct frt_multi_renderer {
@@ -48,6 +62,10 @@ struct frt_multi_renderer {
     std::vector<uint32_t> bounds;
     uint32_t frame = 0;              // frames rendered since create / reset (== every strip's frame_count)
     uint64_t serial = 0;             // frames rendered since create (never reset)
+    // worker threads: `job` counts the steps posted so far (two per frame); a worker runs step `job` when it sees the counter move
+    std::mutex mu; std::condition_variable cv_post, cv_done;
+    uint64_t job = 0; uint32_t done = 0; bool stop = false;
+    frt_camera_uniform cam{};
 };
 
 namespace {
@@ -114,12 +132,9 @@ uint32_t bpp_of_buf(int buf) {
 
 // rows [y0, y1) of `buf`[index]: from strip `src` into the same image rows of strip `dst`, on dst's copy stream
 int copy_rows(frt_multi_renderer* m, Strip& src, Strip& dst, int buf, int index, uint32_t y0, uint32_t y1) {
-    void *ps = nullptr, *pd = nullptr;
-    uint32_t bpp = 0;
-    int rc = frt_renderer_buffer_info(src.r, buf, index, &ps, &bpp);
-    if (rc) return rc;
-    rc = frt_renderer_buffer_info(dst.r, buf, index, &pd, &bpp);
-    if (rc) return rc;
+    const uint32_t bpp = bpp_of_buf(buf);
+    const void* ps = buf == FRT_BUF_RESERVOIR ? src.p_res[index & 1] : src.p_acc[index & 1];
+    void* pd = buf == FRT_BUF_RESERVOIR ? dst.p_res[index & 1] : dst.p_acc[index & 1];
     const size_t pitch = (size_t)m->W * bpp, off = pitch * y0, bytes = pitch * (y1 - y0);
     if (src.device == dst.device) HIPM_TRY(hipMemcpyAsync((uint8_t*)pd + off, (const uint8_t*)ps + off, bytes, hipMemcpyDeviceToDevice, dst.copy));
     else HIPM_TRY(hipMemcpyPeerAsync((uint8_t*)pd + off, dst.device, (const uint8_t*)ps + off, src.device, bytes, dst.copy));
@@ -130,26 +145,99 @@ int copy_rows(frt_multi_renderer* m, Strip& src, Strip& dst, int buf, int index,
 // src_ev(strip): the event behind the kernel that produced the rows; dst_ev(strip): an event of the receiver's main stream behind the last
 // reader of the halo rows; done(strip): the event recorded behind the strip's incoming copies.
 enum Which { PRE, MID, POST };
-int exchange(frt_multi_renderer* m, Which which, int buf, int index, uint32_t rows) {
+// Strip k's INCOMING rows of one exchange (run by strip k's worker).
+int exchange_into(frt_multi_renderer* m, size_t k, Which which, int buf, int index, uint32_t rows) {
     const size_t n = m->strips.size();
-    for (size_t k = 0; k < n; ++k) {
-        Strip& d = m->strips[k];
-        DevGuard g(d.device);
-        hipEvent_t own = which == MID ? d.ev_tm : (which == PRE ? d.ev_spatial : d.ev_post);
-        hipEvent_t done = which == MID ? d.ev_copy_mid : (which == PRE ? d.ev_copy_pre : d.ev_copy_post);
-        HIPM_TRY(hipStreamWaitEvent(d.copy, own, 0));
-        for (int side = 0; side < 2; ++side) {
-            if ((side == 0 && k == 0) || (side == 1 && k + 1 == n)) continue;
-            Strip& s = m->strips[side == 0 ? k - 1 : k + 1];
-            hipEvent_t produced = which == MID ? s.ev_tm : (which == PRE ? s.ev_spatial : s.ev_post);
-            HIPM_TRY(hipStreamWaitEvent(d.copy, produced, 0));
-            // the upper neighbour's last `rows` rows land in [rb - rows, rb); the lower neighbour's first `rows` rows in [re, re + rows)
-            const uint32_t y0 = side == 0 ? d.rb - rows : d.re, y1 = side == 0 ? d.rb : d.re + rows;
-            const int rc = copy_rows(m, s, d, buf, index, y0, y1);
-            if (rc) return rc;
-        }
-        HIPM_TRY(hipEventRecord(done, d.copy));
+    Strip& d = m->strips[k];
+    DevGuard g(d.device);
+    hipEvent_t own = which == MID ? d.ev_tm : (which == PRE ? d.ev_spatial : d.ev_post);
+    hipEvent_t done = which == MID ? d.ev_copy_mid : (which == PRE ? d.ev_copy_pre : d.ev_copy_post);
+    HIPM_TRY(hipStreamWaitEvent(d.copy, own, 0));
+    for (int side = 0; side < 2; ++side) {
+        if ((side == 0 && k == 0) || (side == 1 && k + 1 == n)) continue;
+        Strip& s = m->strips[side == 0 ? k - 1 : k + 1];
+        hipEvent_t produced = which == MID ? s.ev_tm : (which == PRE ? s.ev_spatial : s.ev_post);
+        HIPM_TRY(hipStreamWaitEvent(d.copy, produced, 0));
+        // the upper neighbour's last `rows` rows land in [rb - rows, rb); the lower neighbour's first `rows` rows in [re, re + rows)
+        const uint32_t y0 = side == 0 ? d.rb - rows : d.re, y1 = side == 0 ? d.rb : d.re + rows;
+        const int rc = copy_rows(m, s, d, buf, index, y0, y1);
+        if (rc) return rc;
     }
+    HIPM_TRY(hipEventRecord(done, d.copy));
+    return FRT_OK;
+}
+
+// The two steps of a frame for strip k (see the head of this file). m->frame / m->serial are those of the frame being enqueued.
+int strip_step(frt_multi_renderer* m, size_t k, int step) {
+    Strip& s = m->strips[k];
+    const frt_camera_uniform* cam = &m->cam;
+    const uint32_t K = m->motion_halo;
+    const bool prev = m->serial > 0 && m->frame > 0;      // a previous frame's rows exist (not after create / reset)
+    DevGuard g(s.device);
+    hipStream_t q = (hipStream_t)frt_renderer_stream(s.r, 0);
+    int rc;
+    if (step == 0) {
+        if (prev) {
+            rc = exchange_into(m, k, POST, FRT_BUF_ACCUM, (int)((m->frame - 1u) & 1u), K ? K + kHaloHistory : kHaloHistory);      // a whole frame of slack
+            if (rc) return rc;
+            if (K) {
+                rc = exchange_into(m, k, PRE, FRT_BUF_RESERVOIR, 1, K);
+                if (rc) return rc;
+                HIPM_TRY(hipStreamWaitEvent(q, s.ev_copy_pre, 0));
+            }
+        }
+        rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_GBUFFER | FRT_PHASE_TEMPORAL);      // T-merge (G-buffer + T-trace normally ran ahead of the frame)
+        if (rc) return rc;
+        HIPM_TRY(hipEventRecord(s.ev_tm, q));
+        return FRT_OK;
+    }
+    rc = exchange_into(m, k, MID, FRT_BUF_RESERVOIR, 0, kHaloReservoir);      // behind this strip's and its neighbours' T-merge
+    if (rc) return rc;
+    rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_SPATIAL_INNER);       // interior rows: need nothing from a neighbour
+    if (rc) return rc;
+    HIPM_TRY(hipStreamWaitEvent((hipStream_t)frt_renderer_stream(s.r, 2), s.ev_copy_mid, 0));      // the edge rows' stream waits for the neighbours' reservoirs
+    rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_SPATIAL_EDGE);
+    if (rc) return rc;
+    HIPM_TRY(hipEventRecord(s.ev_spatial, q));
+    if (prev) HIPM_TRY(hipStreamWaitEvent(q, s.ev_copy_post, 0));
+    rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_POST);
+    if (rc) return rc;
+    HIPM_TRY(hipEventRecord(s.ev_post, q));
+    return frt_renderer_end_frame(s.r);
+}
+
+void worker_main(frt_multi_renderer* m, size_t k) {
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(m->mu);
+            m->cv_post.wait(lk, [&] { return m->stop || m->job != seen; });
+            if (m->stop) return;
+            seen = m->job;
+        }
+        const int rc = strip_step(m, k, (int)((seen - 1u) & 1u));
+        Strip& s = m->strips[k];
+        s.status = rc;
+        if (rc) s.message = frt_last_error();      // (thread-local in the library: copy it out of this thread)
+        {
+            std::lock_guard<std::mutex> lk(m->mu);
+            if (++m->done == m->strips.size()) m->cv_done.notify_all();
+        }
+    }
+}
+
+// Run one step on every strip's worker and wait until all have enqueued it.
+int run_step(frt_multi_renderer* m) {
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->done = 0; m->job += 1;
+    }
+    m->cv_post.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(m->mu);
+        m->cv_done.wait(lk, [&] { return m->done == m->strips.size(); });
+    }
+    for (Strip& s : m->strips) if (s.status) return set_error(s.status, s.message);
     return FRT_OK;
 }
 }   // namespace
@@ -190,7 +278,13 @@ frt_multi_renderer* frt_multi_renderer_create(const frt_scene* scene, uint32_t w
         for (hipEvent_t* e : {&s.ev_tm, &s.ev_spatial, &s.ev_post, &s.ev_copy_pre, &s.ev_copy_mid, &s.ev_copy_post})
             ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
         if (!ok) { set_error(FRT_ERR_HIP, "multi_renderer_create: stream / event creation failed"); frt_multi_renderer_destroy(m); return nullptr; }
+        uint32_t bpp = 0;
+        for (int i = 0; i < 2; ++i)
+            if (frt_renderer_buffer_info(s.r, FRT_BUF_RESERVOIR, i, &s.p_res[i], &bpp) != FRT_OK || frt_renderer_buffer_info(s.r, FRT_BUF_ACCUM, i, &s.p_acc[i], &bpp) != FRT_OK) {
+                frt_multi_renderer_destroy(m); return nullptr;
+            }
     }
+    if (ndev > 1) for (uint32_t k = 0; k < ndev; ++k) m->strips[k].worker = std::thread(worker_main, m, (size_t)k);
     // peer access between neighbouring strips on different devices (hipMemcpyPeerAsync works without it, through a staging buffer; with it
     // the rows go straight over xGMI)
     for (uint32_t k = 0; k + 1 < ndev; ++k) {
@@ -206,6 +300,12 @@ frt_multi_renderer* frt_multi_renderer_create(const frt_scene* scene, uint32_t w
 
 void frt_multi_renderer_destroy(frt_multi_renderer* m) {
     if (!m) return;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->stop = true;
+    }
+    m->cv_post.notify_all();
+    for (Strip& s : m->strips) if (s.worker.joinable()) s.worker.join();
     for (Strip& s : m->strips) {
         DevGuard g(s.device);
         if (s.r) (void)frt_renderer_sync(s.r);
@@ -216,51 +316,15 @@ void frt_multi_renderer_destroy(frt_multi_renderer* m) {
     delete m;
 }
 
-// Renderer::render, src/renderer.rs:349 — ONE call, one frame, on every device. Asynchronous.
+// Renderer::render, src/renderer.rs:349 — ONE call, one frame, on every device. Asynchronous on the GPUs (returns when the frame is enqueued).
 int frt_multi_renderer_render(frt_multi_renderer* m, const frt_camera_uniform* cam) {
     if (!m || !cam) return set_error(FRT_ERR_INVALID_ARG, "multi render: null");
-    const size_t n = m->strips.size();
-    if (n == 1) { const int rc = frt_renderer_render(m->strips[0].r, cam); if (rc == FRT_OK) { m->frame += 1; m->serial += 1; } return rc; }
-    const uint32_t K = m->motion_halo;
-    const bool first = m->serial == 0;      // nothing of a previous frame exists yet (events unrecorded, buffers zero)
-    int rc;
-    // "post": the previous frame's accumulation rows (source: post(f-1)); a whole frame of slack. "pre": previous spatial reservoirs.
-    if (!first && m->frame > 0) {
-        rc = exchange(m, POST, FRT_BUF_ACCUM, (int)((m->frame - 1u) & 1u), K ? K + kHaloHistory : kHaloHistory);
-        if (rc) return rc;
-        if (K) { rc = exchange(m, PRE, FRT_BUF_RESERVOIR, 1, K); if (rc) return rc; }
-    }
-    for (Strip& s : m->strips) {      // G-buffer + T-trace (normally already done, ahead of the frame) and T-merge
-        DevGuard g(s.device);
-        hipStream_t q = (hipStream_t)frt_renderer_stream(s.r, 0);
-        if (!first && m->frame > 0 && K) HIPM_TRY(hipStreamWaitEvent(q, s.ev_copy_pre, 0));
-        rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_GBUFFER | FRT_PHASE_TEMPORAL);
-        if (rc) return rc;
-        HIPM_TRY(hipEventRecord(s.ev_tm, q));
-    }
-    rc = exchange(m, MID, FRT_BUF_RESERVOIR, 0, kHaloReservoir);      // behind every strip's T-merge
+    if (m->strips.size() == 1) { const int rc = frt_renderer_render(m->strips[0].r, cam); if (rc == FRT_OK) { m->frame += 1; m->serial += 1; } return rc; }
+    m->cam = *cam;
+    int rc = run_step(m);      // step A on every strip; the return is the host barrier: every ev_tm is recorded
     if (rc) return rc;
-    for (Strip& s : m->strips) {      // interior rows: need nothing from a neighbour
-        rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_SPATIAL_INNER);
-        if (rc) return rc;
-    }
-    for (Strip& s : m->strips) {      // edge rows (their own stream, behind the arrival of the neighbours' reservoirs) + continuations
-        DevGuard g(s.device);
-        HIPM_TRY(hipStreamWaitEvent((hipStream_t)frt_renderer_stream(s.r, 2), s.ev_copy_mid, 0));
-        rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_SPATIAL_EDGE);
-        if (rc) return rc;
-        HIPM_TRY(hipEventRecord(s.ev_spatial, (hipStream_t)frt_renderer_stream(s.r, 0)));
-    }
-    for (Strip& s : m->strips) {
-        DevGuard g(s.device);
-        hipStream_t q = (hipStream_t)frt_renderer_stream(s.r, 0);
-        if (!first && m->frame > 0) HIPM_TRY(hipStreamWaitEvent(q, s.ev_copy_post, 0));
-        rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_POST);
-        if (rc) return rc;
-        HIPM_TRY(hipEventRecord(s.ev_post, q));
-        rc = frt_renderer_end_frame(s.r);
-        if (rc) return rc;
-    }
+    rc = run_step(m);          // step B
+    if (rc) return rc;
     m->frame += 1; m->serial += 1;
     return FRT_OK;
 }
