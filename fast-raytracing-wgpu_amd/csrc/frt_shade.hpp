@@ -59,8 +59,27 @@ struct PathCtx {
     // The two ray queries of the shaders (rayQueryInitialize ... rayQueryGetCommittedIntersection). Functions that trace are templates on
     // the context type and call these, so that a kernel can substitute its own traversal (frt_kernels.hip: ResidentCtx walks a BVH cached in LDS).
     // Default: the quad tree (frt_trace.hpp: trace4).
-    FRT_HD void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) { n_closest++; trace4<false>(sc, o, d, tmin, tmax, stk, stride, h); }
-    FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) { HitRec h; n_any++; trace4<true>(sc, o, d, tmin, tmax, stk, stride, h); return h.tri != 0xFFFFFFFFu; }
+    // FRT_DBG_TWICE (timing builds only, tools/abrun.sh): bit 0 walks every closest-hit ray of the traced stages twice, bit 1 every any-hit ray; the
+    // second walk's result is discarded, so the frame-time difference IS the time the renderer spends in traversal — measured in place, beside the
+    // shading it shares the CU with (profiles/r3_experiments/traversal_in_situ.md: 0.52 + 0.49 ms of the 1.68 ms the traced stages take on one stream).
+#ifndef FRT_DBG_TWICE
+#define FRT_DBG_TWICE 0
+#endif
+    FRT_HD void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) {
+        n_closest++;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (FRT_DBG_TWICE & 1) { HitRec h2; f3 o2 = o; asm volatile("" : "+v"(o2.x)); trace4<false>(sc, o2, d, tmin, tmax, stk, stride, h2); asm volatile("" :: "v"(h2.t), "v"(h2.tri)); }
+#endif
+        trace4<false>(sc, o, d, tmin, tmax, stk, stride, h);
+    }
+    FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) {
+        HitRec h; n_any++;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (FRT_DBG_TWICE & 2) { HitRec h2; f3 o2 = o; asm volatile("" : "+v"(o2.x)); trace4<true>(sc, o2, d, tmin, tmax, stk, stride, h2); asm volatile("" :: "v"(h2.tri)); }
+#endif
+        trace4<true>(sc, o, d, tmin, tmax, stk, stride, h);
+        return h.tri != 0xFFFFFFFFu;
+    }
 };
 
 FRT_HD float rand_lcg(uint32_t& state) {   // restir.wgsl:781-786

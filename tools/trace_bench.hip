@@ -61,6 +61,16 @@ __global__ void __launch_bounds__(256, 4) bench_kernel(SceneView sc, QQuadView q
             trace4_postpone<true>(sc, mk3(a.ox, a.oy, a.oz), mk3(a.dx, a.dy, a.dz), a.tmin, a.tmax, stk, 256u, ha);
             occluded = ha.tri != 0xFFFFFFFFu;
             trace4_postpone<false>(sc, mk3(b.ox, b.oy, b.oz), mk3(b.dx, b.dy, b.dz), b.tmin, b.tmax, stk, 256u, hb);
+        } else if (VARIANT == 7 || VARIANT == 9) {      // every ray votes (7: plain majority, 9: a node step counts 1.5 x)
+            constexpr int WN = VARIANT == 7 ? 2 : 3;
+            trace4_vote<true, WN, 2>(sc, mk3(a.ox, a.oy, a.oz), mk3(a.dx, a.dy, a.dz), a.tmin, a.tmax, stk, 256u, ha);
+            occluded = ha.tri != 0xFFFFFFFFu;
+            trace4_vote<false, WN, 2>(sc, mk3(b.ox, b.oy, b.oz), mk3(b.dx, b.dy, b.dz), b.tmin, b.tmax, stk, 256u, hb);
+        } else if (VARIANT == 8 || VARIANT == 10) {     // shadow rays while-while (the model says voting costs them 4 %), closest-hit rays vote
+            constexpr int WN = VARIANT == 8 ? 2 : 3;
+            trace4<true>(sc, mk3(a.ox, a.oy, a.oz), mk3(a.dx, a.dy, a.dz), a.tmin, a.tmax, stk, 256u, ha);
+            occluded = ha.tri != 0xFFFFFFFFu;
+            trace4_vote<false, WN, 2>(sc, mk3(b.ox, b.oy, b.oz), mk3(b.dx, b.dy, b.dz), b.tmin, b.tmax, stk, 256u, hb);
         } else if (VARIANT == 4) {
             trace4_xload<true>(sc, mk3(a.ox, a.oy, a.oz), mk3(a.dx, a.dy, a.dz), a.tmin, a.tmax, stk, 256u, ha);
             occluded = ha.tri != 0xFFFFFFFFu;
@@ -110,7 +120,7 @@ static double run(const char* name, const SceneView& sv, const RayRec* d_sh, con
     res = Out{};
     for (const Out& o : parts) { res.occluded += o.occluded; res.hits += o.hits; res.tri_sum += o.tri_sum; res.t_sum += o.t_sum; }
     printf("%-10s %8.3f ms  %7.2f Grays/s  occluded %llu hits %llu tri_sum %llu t_sum %llu\n", name, best, 2.0 * n / (best * 1e-3) / 1e9, res.occluded, res.hits, res.tri_sum, res.t_sum);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return best;
 }
 
@@ -250,6 +260,10 @@ int main(int argc, char** argv) {
     if (only < 0 || only == 4) { run<4>("early+4ld", sv, d_sh, d_cl, n, d_out, r); }
     if (only < 0 || only == 5) { run<5>("q16 4ld", sv, d_sh, d_cl, n, d_out, r); ok &= same(r); }
     if (only < 0 || only == 6) { run<6>("postpone", sv, d_sh, d_cl, n, d_out, r); ok &= same(r); }
+    if (only < 0 || only == 7) { run<7>("vote", sv, d_sh, d_cl, n, d_out, r); ok &= same(r); }
+    if (only < 0 || only == 8) { run<8>("vote cl", sv, d_sh, d_cl, n, d_out, r); ok &= same(r); }
+    if (only < 0 || only == 9) { run<9>("vote 3:2", sv, d_sh, d_cl, n, d_out, r); ok &= same(r); }
+    if (only < 0 || only == 10) { run<10>("vote3:2 cl", sv, d_sh, d_cl, n, d_out, r); ok &= same(r); }
     printf(ok ? "checksums equal\n" : "CHECKSUM MISMATCH\n");
     return ok ? 0 : 2;
 }

@@ -499,3 +499,64 @@ __device__ __forceinline__ void trace4_postpone(const SceneView& sc, f3 o, f3 d,
         hit.front = front;
     }
 }
+
+// ---- variant 7 / 8: the wave VOTES for its next step --------------------------------------------------------------------------------------
+// trace4 is "while-while": node steps until no lane of the wave holds a node, then one leaf step. A lane's own sequence of node and leaf steps
+// does not depend on how the wave interleaves them, so the wave's schedule is a common supersequence of its lanes' sequences, and while-while
+// is only one way to build it: tools/bvh_quality.cpp (host model of the lockstep walk) finds 9.9 node + 3.3 leaf steps per wave-ray for
+// incoherent rays where the slowest lane needs 7.0 node steps. Here every trip of ONE loop takes the step that more lanes wait for (weights WN :
+// WL), which the model puts at 8.0 + 4.0.
+template <bool ANY, int WN, int WL>
+__device__ __forceinline__ void trace4_vote(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint32_t* stk, uint32_t stride, HitRec& hit) {
+    hit.t = tmax; hit.tri = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f; hit.inst = 0u; hit.front = false;
+    float best_det = 0.0f;
+    const RaySetup rs = ray_setup(o, d);
+    const uint32_t kDone = 0xFFFFFFFFu;
+    const float kFar = 3.0e38f;
+    uint32_t* top = stk;
+    const char* nb = reinterpret_cast<const char*>(sc.nodes4);
+    uint32_t cur = 0u;
+    auto test = [&](uint32_t slot) -> bool {
+        const float4* tp = sc.tris + (size_t)slot * 3u;
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        float t, u, v, det;
+        if (intersect_tri(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, d, tmin, tmax, t, u, v, det)) {
+            const uint32_t id = f2u(a.w);
+            if (ANY) { hit.tri = id; hit.t = t; return true; }
+            if (t < hit.t || (t == hit.t && id < hit.tri)) { hit.t = t; hit.u = u; hit.v = v; hit.tri = id; hit.inst = f2u(b.w); best_det = det; }
+        }
+        return false;
+    };
+    for (;;) {
+        const bool at_node = !(cur & 0x80000000u);
+        const bool at_leaf = !at_node && cur != kDone;
+        const unsigned long long mn = __ballot(at_node), ml = __ballot(at_leaf);
+        if ((mn | ml) == 0ull) break;
+        const bool do_node = ml == 0ull || (mn != 0ull && __popcll(mn) * WN >= __popcll(ml) * WL);      // wave-uniform
+        if (do_node) {
+            if (at_node) {
+                const NodeRegs n = node_fetch(nb, cur << 7, rs);
+                float k[4]; uint32_t r[4];
+                node_eval(n, rs, tmin, ANY ? tmax : hit.t, k, r);
+                if (k[3] < kFar) { *top = r[3]; top += stride; }
+                if (k[2] < kFar) { *top = r[2]; top += stride; }
+                if (k[1] < kFar) { *top = r[1]; top += stride; }
+                if (k[0] < kFar) cur = r[0];
+                else if (top == stk) cur = kDone;
+                else { top -= stride; cur = *top; }
+            }
+        } else if (at_leaf) {
+            const uint32_t first = cur & 0x00FFFFFFu, count = (cur >> 24) & 0x7Fu;
+            bool found = test(first);
+            if (!found && count > 1u) found = test(first + 1u);
+            for (uint32_t kk = 2u; !found && kk < count; ++kk) found = test(first + kk);
+            if (found || top == stk) cur = kDone;
+            else { top -= stride; cur = *top; }
+        }
+    }
+    if (!ANY && hit.tri != 0xFFFFFFFFu) {
+        bool front = best_det > 0.0f;
+        if (sc.instances[hit.inst].flip) front = !front;
+        hit.front = front;
+    }
+}
