@@ -1,7 +1,7 @@
 // bvh_quality.cpp — offline measure of what a BVH costs the traced kernels, on the host (no GPU).
 //
 //   g++ -O2 -std=c++17 tools/bvh_quality.cpp -Iinclude -Lfast-raytracing-wgpu_amd/lib -lfrt -Wl,-rpath,$PWD/fast-raytracing-wgpu_amd/lib -o tools/_build/bvh_quality
-//   tools/_build/bvh_quality [cornell|restir] [tiles] [insertion passes] [policy 0|1|2] [threshold]
+//   tools/_build/bvh_quality [cornell|restir] [tiles] [insertion passes] [policy 0|1|2] [threshold] [presence 0..1] [split 0|1]
 //
 // Takes the canonical BVH2 the product built (frt_scene_get), folds it into quad nodes the way frt_bvh.cpp: build_quad_nodes does, and walks it
 // with the rays of the workload — 8x8 pixel tiles of primary rays from the benchmark camera, then from every primary hit a cosine-distributed
@@ -102,8 +102,10 @@ struct Lane {
     V3 o, d, inv; float tmin, tmax, best; bool any, done; uint32_t cur, hit;
     std::vector<uint32_t> stk;
     uint64_t node_steps = 0, tri_tests = 0;
+    int grp_size = 1, grp_rank = 0;      // ray splitting: this lane walks every grp_size-th hit child of the root, starting with the grp_rank-th nearest
+    float* shared_best = nullptr;        // closest-hit rays: the group's common tmax (a cross-lane min per step on the GPU)
     void start(V3 o_, V3 d_, float tmin_, float tmax_, bool any_) {
-        o = o_; d = d_; tmin = tmin_; tmax = tmax_; any = any_; best = tmax_; done = false; cur = 0; hit = kNone; stk.clear();
+        o = o_; d = d_; tmin = tmin_; tmax = tmax_; any = any_; best = tmax_; done = false; cur = 0; hit = kNone; stk.clear(); grp_size = 1; grp_rank = 0; shared_best = nullptr;
         auto rc = [](float x) { const float k = 8.271806125530277e-25f; return 1.0f / (std::fabs(x) > k ? x : std::copysign(k, x)); };
         inv = {rc(d.x), rc(d.y), rc(d.z)};
         node_steps = tri_tests = 0;
@@ -117,7 +119,7 @@ struct Lane {
         float key[4]; uint32_t r[4];
         const float o3[3] = {o.x, o.y, o.z}, i3[3] = {inv.x, inv.y, inv.z};
         for (int c = 0; c < 4; ++c) {
-            float tn = tmin, tf = any ? tmax : best;
+            float tn = tmin, tf = any ? tmax : (shared_best ? std::min(best, *shared_best) : best);
             for (int a = 0; a < 3; ++a) {
                 float t0 = (q.lo[a][c] - o3[a]) * i3[a], t1 = (q.hi[a][c] - o3[a]) * i3[a];
                 tn = std::max(tn, std::min(t0, t1)); tf = std::min(tf, std::max(t0, t1));
@@ -126,6 +128,14 @@ struct Lane {
         }
         auto ce = [&](int a, int b) { if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(r[a], r[b]); } };
         ce(0, 1); ce(2, 3); ce(0, 2); ce(1, 3); ce(1, 2);
+        if (cur == 0 && grp_size > 1) {      // the root's hit children, near to far, dealt round-robin to the lanes of the group
+            int nh = 0; while (nh < 4 && key[nh] < 3e38f) ++nh;
+            std::vector<uint32_t> mine;
+            for (int c = grp_rank; c < nh; c += grp_size) mine.push_back(r[c]);
+            for (size_t c = mine.size(); c-- > 1;) stk.push_back(mine[c]);
+            if (!mine.empty()) cur = mine[0]; else pop();
+            return;
+        }
         for (int c = 3; c >= 1; --c) if (key[c] < 3e38f) stk.push_back(r[c]);
         if (key[0] < 3e38f) cur = r[0]; else pop();
     }
@@ -144,7 +154,7 @@ struct Lane {
             float t = dot(tr.e2, qq) * iv;
             if (!(t > tmin && t < tmax)) continue;
             if (any) { hit = id; done = true; return; }
-            if (t < best || (t == best && id < hit)) { best = t; hit = id; }
+            if (t < best || (t == best && id < hit)) { best = t; hit = id; if (shared_best && t < *shared_best) *shared_best = t; }
         }
         pop();
     }
@@ -190,6 +200,8 @@ static void run_wave(const Tree& T, std::vector<Lane>& L, const std::vector<char
     w.max_lane_nodes += mx;
 }
 
+static float g_presence = 1.0f;      // fraction of the lanes that bring a ray to a walk (the renderer: 0.5 - 0.65)
+static int g_split = 0;              // 1: idle lanes help — a ray's root children are dealt to 2 or 4 lanes
 static uint32_t rng_state = 12345u;
 static float rnd() { rng_state = rng_state * 747796405u + 2891336453u; uint32_t w = ((rng_state >> ((rng_state >> 28) + 4)) ^ rng_state) * 277803737u; return (float)((w >> 22) ^ w) / 4294967296.0f; }
 static V3 cosine_dir(V3 n) {
@@ -197,12 +209,44 @@ static V3 cosine_dir(V3 n) {
     return norm(n + V3{r * std::cos(a), r * std::sin(a), z});
 }
 
+// A walk of the rays in `L` (act = lane brings a ray; thinned here to the presence asked for) and, optionally, ray splitting over the idle lanes.
+// Results (hit, best) end up in L as if every ray had walked alone.
+static void run_walk(const Tree& T, std::vector<Lane>& L, std::vector<char>& act, WaveCost& w) {
+    for (size_t i = 0; i < L.size(); ++i) if (act[i] && rnd() > g_presence) { act[i] = 0; L[i].hit = kNone; }
+    if (!g_split) { run_wave(T, L, act, w); return; }
+    std::vector<int> rays;
+    for (size_t i = 0; i < L.size(); ++i) if (act[i]) rays.push_back((int)i);
+    const int n = (int)rays.size();
+    if (n == 0) return;
+    // lanes per ray: 1, 2 or 4, as many as fit; the first rays get the larger share
+    std::vector<int> share(n, 1);
+    int freel = 64 - n;
+    for (int pass = 0; pass < 2; ++pass) for (int k = 0; k < n; ++k) { const int add = share[k]; if (freel >= add) { share[k] += add; freel -= add; } }
+    std::vector<Lane> G; std::vector<char> gact; std::vector<int> owner;
+    std::vector<float> shared(n, 0.0f);
+    for (int k = 0; k < n; ++k) {
+        const Lane& src = L[rays[k]];
+        shared[k] = src.tmax;
+        for (int j = 0; j < share[k]; ++j) { Lane l = src; l.grp_size = share[k]; l.grp_rank = j; l.shared_best = src.any ? nullptr : &shared[k]; G.push_back(l); gact.push_back(1); owner.push_back(k); }
+    }
+    while (G.size() < 64) { G.push_back(L[rays[0]]); gact.push_back(0); owner.push_back(-1); }
+    const uint64_t rays_before = w.rays;
+    run_wave(T, G, gact, w);
+    w.rays = rays_before + (uint64_t)n;      // (run_wave counted lanes)
+    for (int k = 0; k < n; ++k) { L[rays[k]].hit = kNone; L[rays[k]].best = L[rays[k]].tmax; }
+    for (size_t g = 0; g < G.size(); ++g) if (gact[g] && G[g].hit != kNone) {
+        Lane& dst = L[rays[owner[g]]];
+        if (dst.hit == kNone || G[g].best < dst.best || (G[g].best == dst.best && G[g].hit < dst.hit)) { dst.hit = G[g].hit; dst.best = G[g].best; }
+    }
+}
+
 static void report(const char* name, const WaveCost& w) {
     if (!w.rays) return;
-    printf("  %-10s rays %8llu  per lane-ray: nodes %6.2f tris %5.2f | per wave-ray: node steps %6.2f leaf steps %5.2f  tri tests %5.2f (slowest lane %6.2f)  cost~ %7.1f\n", name,
+    printf("  %-10s rays %8llu  per lane-ray: nodes %6.2f tris %5.2f | per wave-ray: node steps %6.2f leaf steps %5.2f  tri tests %5.2f (slowest lane %6.2f)  cost~ %7.1f  per 64 rays %7.1f\n", name,
            (unsigned long long)w.rays, (double)w.lane_nodes / w.rays, (double)w.lane_tris / w.rays, (double)w.wave_nodes / w.wave_rays,
            (double)w.wave_leaves / w.wave_rays, (double)w.wave_tri_tests / w.wave_rays, (double)w.max_lane_nodes / w.wave_rays,
-           (110.0 * w.wave_nodes + 20.0 * w.wave_leaves + 75.0 * w.wave_tri_tests) / w.wave_rays);      // VALU + SALU per step, from the ISA of trace4
+           (110.0 * w.wave_nodes + 20.0 * w.wave_leaves + 75.0 * w.wave_tri_tests) / w.wave_rays,
+           (110.0 * w.wave_nodes + 20.0 * w.wave_leaves + 75.0 * w.wave_tri_tests) / w.rays * 64.0);      // VALU + SALU per step, from the ISA of trace4
 }
 
 int main(int argc, char** argv) {
@@ -223,6 +267,8 @@ int main(int argc, char** argv) {
     const int passes = argc > 3 ? atoi(argv[3]) : 0;
     g_policy = argc > 4 ? atoi(argv[4]) : 0;
     g_thresh = argc > 5 ? atoi(argv[5]) : 16;
+    g_presence = argc > 6 ? (float)atof(argv[6]) : 1.0f;
+    g_split = argc > 7 ? atoi(argv[7]) : 0;
     if (passes > 0) {
         printf("as built: SAH cost %.3f depth %u; ", sah_cost(T.t), st[0]);
         st[0] = frt::optimize_bvh2(T.t, T.tri_index, passes, 30u, st[0]);
@@ -268,9 +314,9 @@ int main(int argc, char** argv) {
             if (dot(N[i], d) <= 0) continue;
             L[i].start(op, d * (1.0f / dist), 0.001f, dist * 0.999f, true); act2[i] = 1;
         }
-        run_wave(T, L, act2, shadow);
+        run_walk(T, L, act2, shadow);
         for (int i = 0; i < 64; ++i) if (act[i]) L[i].start(P[i] + N[i] * 0.001f, cosine_dir(N[i]), 0.001f, 100.0f, false);
-        run_wave(T, L, act, bounce1);
+        run_walk(T, L, act, bounce1);
         for (int i = 0; i < 64; ++i) {
             bool a = act[i] && L[i].hit != kNone;
             if (a) {
@@ -282,7 +328,7 @@ int main(int argc, char** argv) {
             }
             act[i] = a;
         }
-        run_wave(T, L, act, bounce2);
+        run_walk(T, L, act, bounce2);
     }
     report("primary", primary); report("shadow", shadow); report("bounce 1", bounce1); report("bounce 2", bounce2);
     WaveCost all;
