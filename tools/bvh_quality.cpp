@@ -1,7 +1,7 @@
 // bvh_quality.cpp — offline measure of what a BVH costs the traced kernels, on the host (no GPU).
 //
 //   g++ -O2 -std=c++17 tools/bvh_quality.cpp -Iinclude -Lfast-raytracing-wgpu_amd/lib -lfrt -Wl,-rpath,$PWD/fast-raytracing-wgpu_amd/lib -o tools/_build/bvh_quality
-//   tools/_build/bvh_quality [cornell|restir] [tiles] [insertion passes] [policy 0|1|2] [threshold] [presence 0..1] [split 0|1]
+//   tools/_build/bvh_quality [cornell|restir] [tiles] [insertion passes] [policy 0|1|2] [threshold] [presence 0..1] [split 0|1] [chain 0|1]
 //
 // Takes the canonical BVH2 the product built (frt_scene_get), folds it into quad nodes the way frt_bvh.cpp: build_quad_nodes does, and walks it
 // with the rays of the workload — 8x8 pixel tiles of primary rays from the benchmark camera, then from every primary hit a cosine-distributed
@@ -104,15 +104,25 @@ struct Lane {
     uint64_t node_steps = 0, tri_tests = 0;
     int grp_size = 1, grp_rank = 0;      // ray splitting: this lane walks every grp_size-th hit child of the root, starting with the grp_rank-th nearest
     float* shared_best = nullptr;        // closest-hit rays: the group's common tmax (a cross-lane min per step on the GPU)
+    bool has_next = false; V3 no, nd; float ntmin = 0, ntmax = 0; bool nany = false;      // chained walk: the lane's NEXT ray starts when this one ends, without waiting for the wave
+    bool first_occluded = false; uint64_t node_steps_total = 0, tri_tests_total = 0;
     void start(V3 o_, V3 d_, float tmin_, float tmax_, bool any_) {
-        o = o_; d = d_; tmin = tmin_; tmax = tmax_; any = any_; best = tmax_; done = false; cur = 0; hit = kNone; stk.clear(); grp_size = 1; grp_rank = 0; shared_best = nullptr;
+        o = o_; d = d_; tmin = tmin_; tmax = tmax_; any = any_; best = tmax_; done = false; cur = 0; hit = kNone; stk.clear(); grp_size = 1; grp_rank = 0; shared_best = nullptr; has_next = false;
         auto rc = [](float x) { const float k = 8.271806125530277e-25f; return 1.0f / (std::fabs(x) > k ? x : std::copysign(k, x)); };
         inv = {rc(d.x), rc(d.y), rc(d.z)};
         node_steps = tri_tests = 0;
     }
+    void chain(V3 o_, V3 d_, float tmin_, float tmax_, bool any_) { has_next = true; no = o_; nd = d_; ntmin = tmin_; ntmax = tmax_; nany = any_; }
+    void finish() {      // this ray is over: start the chained one, if any
+        if (!has_next) { done = true; return; }
+        first_occluded = hit != kNone;
+        const uint64_t ns = node_steps, ts = tri_tests;
+        start(no, nd, ntmin, ntmax, nany);
+        node_steps = ns; tri_tests = ts;
+    }
     bool at_node() const { return !done && !(cur & kLeaf); }
     bool at_leaf() const { return !done && (cur & kLeaf) && cur != kNone; }
-    void pop() { if (stk.empty()) done = true; else { cur = stk.back(); stk.pop_back(); } }
+    void pop() { if (stk.empty()) finish(); else { cur = stk.back(); stk.pop_back(); } }
     void node_step(const Tree& T) {
         ++node_steps;
         const Quad& q = T.quads[cur];
@@ -153,13 +163,13 @@ struct Lane {
             if (!(v >= 0 && u + v <= 1)) continue;
             float t = dot(tr.e2, qq) * iv;
             if (!(t > tmin && t < tmax)) continue;
-            if (any) { hit = id; done = true; return; }
+            if (any) { hit = id; finish(); return; }
             if (t < best || (t == best && id < hit)) { best = t; hit = id; if (shared_best && t < *shared_best) *shared_best = t; }
         }
         pop();
     }
 };
-struct WaveCost { uint64_t rays = 0, lane_nodes = 0, lane_tris = 0, wave_rays = 0, wave_nodes = 0, wave_leaves = 0, wave_tri_tests = 0, max_lane_nodes = 0; };
+struct WaveCost { uint64_t checksum = 0, rays = 0, lane_nodes = 0, lane_tris = 0, wave_rays = 0, wave_nodes = 0, wave_leaves = 0, wave_tri_tests = 0, max_lane_nodes = 0; };
 static uint32_t leaf_count(uint32_t ref) { return (ref >> 24) & 0x7F; }
 static int g_policy = 0;      // 0: while-while (trace4); 1: majority (the step more lanes wait for); 2: leaf step as soon as fewer than g_thresh lanes hold a node
 static int g_thresh = 16;
@@ -201,6 +211,7 @@ static void run_wave(const Tree& T, std::vector<Lane>& L, const std::vector<char
 }
 
 static float g_presence = 1.0f;      // fraction of the lanes that bring a ray to a walk (the renderer: 0.5 - 0.65)
+static int g_chain = 0;              // 1: the shadow ray and the bounce ray of a lane walked back to back in ONE wave loop (no wait for the wave in between)
 static int g_split = 0;              // 1: idle lanes help — a ray's root children are dealt to 2 or 4 lanes
 static uint32_t rng_state = 12345u;
 static float rnd() { rng_state = rng_state * 747796405u + 2891336453u; uint32_t w = ((rng_state >> ((rng_state >> 28) + 4)) ^ rng_state) * 277803737u; return (float)((w >> 22) ^ w) / 4294967296.0f; }
@@ -213,7 +224,7 @@ static V3 cosine_dir(V3 n) {
 // Results (hit, best) end up in L as if every ray had walked alone.
 static void run_walk(const Tree& T, std::vector<Lane>& L, std::vector<char>& act, WaveCost& w) {
     for (size_t i = 0; i < L.size(); ++i) if (act[i] && rnd() > g_presence) { act[i] = 0; L[i].hit = kNone; }
-    if (!g_split) { run_wave(T, L, act, w); return; }
+    if (!g_split) { run_wave(T, L, act, w); for (size_t i = 0; i < L.size(); ++i) if (act[i]) w.checksum += L[i].any ? (L[i].hit == kNone ? 0u : 1u) : (L[i].hit == kNone ? 0u : L[i].hit + 1u); return; }
     std::vector<int> rays;
     for (size_t i = 0; i < L.size(); ++i) if (act[i]) rays.push_back((int)i);
     const int n = (int)rays.size();
@@ -238,6 +249,7 @@ static void run_walk(const Tree& T, std::vector<Lane>& L, std::vector<char>& act
         Lane& dst = L[rays[owner[g]]];
         if (dst.hit == kNone || G[g].best < dst.best || (G[g].best == dst.best && G[g].hit < dst.hit)) { dst.hit = G[g].hit; dst.best = G[g].best; }
     }
+    for (int k = 0; k < n; ++k) w.checksum += L[rays[k]].any ? (L[rays[k]].hit == kNone ? 0u : 1u) : (L[rays[k]].hit == kNone ? 0u : L[rays[k]].hit + 1u);
 }
 
 static void report(const char* name, const WaveCost& w) {
@@ -269,6 +281,7 @@ int main(int argc, char** argv) {
     g_thresh = argc > 5 ? atoi(argv[5]) : 16;
     g_presence = argc > 6 ? (float)atof(argv[6]) : 1.0f;
     g_split = argc > 7 ? atoi(argv[7]) : 0;
+    g_chain = argc > 8 ? atoi(argv[8]) : 0;
     if (passes > 0) {
         printf("as built: SAH cost %.3f depth %u; ", sah_cost(T.t), st[0]);
         st[0] = frt::optimize_bvh2(T.t, T.tri_index, passes, 30u, st[0]);
@@ -280,7 +293,7 @@ int main(int argc, char** argv) {
     // benchmark camera: (0, 0, 3) looking down -z, 45 degrees vertical, 16:9 (camera.rs:40-42, :218-222)
     const int W = 1920, H = 1080;
     const float th = std::tan(0.5f * 45.0f * 3.14159265f / 180.0f), aspect = (float)W / H;
-    WaveCost primary, bounce1, shadow, bounce2;
+    WaveCost primary, bounce1, shadow, bounce2, chained;
     std::vector<Lane> L(64);
     std::vector<char> act(64), act2(64);
     std::vector<V3> P(64), N(64);
@@ -314,9 +327,23 @@ int main(int argc, char** argv) {
             if (dot(N[i], d) <= 0) continue;
             L[i].start(op, d * (1.0f / dist), 0.001f, dist * 0.999f, true); act2[i] = 1;
         }
+        if (g_chain) {
+            // one walk: lanes with a shadow ray walk it first and go straight on to their bounce ray
+            std::vector<char> actc(64);
+            for (int i = 0; i < 64; ++i) {
+                actc[i] = act[i];
+                if (!act[i]) continue;
+                const V3 bo = P[i] + N[i] * 0.001f, bd = cosine_dir(N[i]);
+                if (act2[i]) L[i].chain(bo, bd, 0.001f, 100.0f, false);      // (L[i] already holds the shadow ray)
+                else L[i].start(bo, bd, 0.001f, 100.0f, false);
+            }
+            run_walk(T, L, actc, chained);
+            act = actc;
+        } else {
         run_walk(T, L, act2, shadow);
         for (int i = 0; i < 64; ++i) if (act[i]) L[i].start(P[i] + N[i] * 0.001f, cosine_dir(N[i]), 0.001f, 100.0f, false);
         run_walk(T, L, act, bounce1);
+        }
         for (int i = 0; i < 64; ++i) {
             bool a = act[i] && L[i].hit != kNone;
             if (a) {
@@ -330,10 +357,14 @@ int main(int argc, char** argv) {
         }
         run_walk(T, L, act, bounce2);
     }
-    report("primary", primary); report("shadow", shadow); report("bounce 1", bounce1); report("bounce 2", bounce2);
+    report("primary", primary); report("shadow", shadow); report("bounce 1", bounce1); report("shadow+b1", chained); report("bounce 2", bounce2);
+    if (!g_chain) { WaveCost sum = shadow; sum.wave_nodes += bounce1.wave_nodes; sum.wave_leaves += bounce1.wave_leaves; sum.wave_tri_tests += bounce1.wave_tri_tests; sum.rays += bounce1.rays;
+                    sum.lane_nodes += bounce1.lane_nodes; sum.lane_tris += bounce1.lane_tris; sum.max_lane_nodes += bounce1.max_lane_nodes; sum.wave_rays = bounce1.wave_rays; report("sh + b1", sum); }
     WaveCost all;
     for (const WaveCost* w : {&shadow, &bounce1, &bounce2}) { all.rays += w->rays; all.lane_nodes += w->lane_nodes; all.lane_tris += w->lane_tris; all.wave_rays += w->wave_rays; all.wave_nodes += w->wave_nodes; all.wave_leaves += w->wave_leaves; all.wave_tri_tests += w->wave_tri_tests; all.max_lane_nodes += w->max_lane_nodes; }
     report("incoherent", all);
+    // what the rays hit does not depend on the schedule, the helpers or the tree: occluded shadow rays + sum of (hit triangle id + 1) over the bounce rays
+    printf("hits checksum %llu %llu %llu\n", (unsigned long long)shadow.checksum, (unsigned long long)bounce1.checksum, (unsigned long long)bounce2.checksum);
     frt_scene_destroy(s);
     return 0;
 }
