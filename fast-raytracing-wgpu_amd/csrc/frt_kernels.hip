@@ -129,7 +129,11 @@ __device__ __forceinline__ bool run_segment_and_park(Ctx& c, LoopState& s, uint3
     return parked;
 }
 
-template <int STAGE>
+// VOTE: the traced kernels of scenes with a deep tree walk it with the voting loop (frt_trace.hpp: trace4<ANY, VOTE>; frt_renderer.hip: kVoteMinQuadNodes).
+template <bool VOTE> struct CtxOf { typedef PathCtx type; };
+template <> struct CtxOf<true> { typedef VotePathCtx type; };
+
+template <int STAGE, bool VOTE>
 __global__ void __launch_bounds__(kBlock, FRT_WAVES) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, uint32_t* zero_counts, bool wg_park) {
     constexpr int THREADS = kBlock;
     __shared__ uint32_t s_stack[kStackDepth * THREADS];
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(kBlock, FRT_WAVES) pixel_kernel(SceneView sc, 
     if (zero_counts && blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x <= (uint32_t)kMaxCuts) zero_counts[threadIdx.x] = 0u;
     uint32_t px, py;
     const bool active = tile_pixel(fv, px, py);      // tile rows top to bottom (a sweep from the expensive end of the image was measured: 1-2 % slower, profiles/r2_experiments)
-    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
+    typename CtxOf<VOTE>::type c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
     const uint32_t pix = py * fv.W + px;
     const bool counted = active && py >= fv.own_y0 && py < fv.own_y1;
     LoopState s;
@@ -180,7 +184,7 @@ __global__ void __launch_bounds__(kBlock, FRT_WAVES) pixel_kernel(SceneView sc, 
 }
 
 // Resumes parked paths for bounces [d0, d1); survivors are parked again in `qout` (d1 < MAX_DEPTH) or finished here.
-template <int STAGE>
+template <int STAGE, bool VOTE>
 __global__ void __launch_bounds__(kBlock, FRT_WAVES) continue_kernel(SceneView sc, FrameView fv, ContQueue qin, ContQueue qout, uint32_t d0, uint32_t d1) {
     constexpr int THREADS = kBlock;
     __shared__ uint32_t s_stack[kStackDepth * THREADS];
@@ -191,7 +195,7 @@ __global__ void __launch_bounds__(kBlock, FRT_WAVES) continue_kernel(SceneView s
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
-    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
+    typename CtxOf<VOTE>::type c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
     uint32_t cnt_closest = 0u, cnt_any = 0u;
     // stride loop: one trip with the grid of launch_trace_continuations; uniform per workgroup for any grid
     for (uint32_t base = blockIdx.x * (uint32_t)THREADS; base < n; base += gridDim.x * (uint32_t)THREADS) {
@@ -330,8 +334,9 @@ hipError_t launch_trace_pixels(int stage, const SceneView& sc, const FrameView& 
 #if FRT_EXPERIMENTS
     if (L.resident) return exp_launch_resident_pixels(stage, sc, fv, stream, L);
 #endif
-    if (stage == 1) hipLaunchKernelGGL(pixel_kernel<1>, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), L.zero_counts, L.wg_park);
-    else hipLaunchKernelGGL(pixel_kernel<2>, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), L.zero_counts, L.wg_park);
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), L.zero_counts, L.wg_park); };
+    if (stage == 1) { if (L.vote) go(pixel_kernel<1, true>); else go(pixel_kernel<1, false>); }
+    else { if (L.vote) go(pixel_kernel<2, true>); else go(pixel_kernel<2, false>); }
     return hipGetLastError();
 }
 bool trace_has_continuations(const TraceLaunch& L, uint32_t max_depth) { return L.ncuts > 0 && L.cuts[0] < max_depth; }
@@ -346,8 +351,9 @@ hipError_t launch_trace_continuations(int stage, const SceneView& sc, const Fram
         const uint32_t gslots = std::max(queue_of(L, k).capacity, L.grid_min_slots);   // (workgroups beyond the queue's fill retire at once)
         const dim3 cgrid((gslots + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
         const uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
-        if (stage == 1) hipLaunchKernelGGL(continue_kernel<1>, cgrid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1);
-        else hipLaunchKernelGGL(continue_kernel<2>, cgrid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1);
+        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, cgrid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1); };
+        if (stage == 1) { if (L.vote) go(continue_kernel<1, true>); else go(continue_kernel<1, false>); }
+        else { if (L.vote) go(continue_kernel<2, true>); else go(continue_kernel<2, false>); }
     }
     return hipGetLastError();
 }

@@ -13,6 +13,7 @@ struct TraceLaunch { uint32_t ncuts; uint32_t cuts[kMaxCuts]; uint32_t* qwords[2
                      uint32_t* zero_counts; uint32_t* tile_state;
                      // resident form (frt_kernels.hip: resident_*_kernel): BVH cached in LDS, persistent workgroups
                      bool wg_park;   // pixel kernel: one queue reservation per workgroup instead of one per wave
+                     bool vote;      // the kernels whose BVH walk votes for its next step (frt_trace.hpp: trace4<ANY, VOTE>): scenes with a deep tree
                      bool wavefront; uint32_t* wf_words[2]; uint32_t* wf_items[2]; uint32_t* wf_hits;   // ray-level wavefront (frt_kernels.hip: wf_*_kernel); counts = its 96-word counter block
                      bool stream; uint32_t shade_min, slice;   // single cut: stream_kernel (resumable traversal + lane refill); shade when >= shade_min lanes wait
                      bool refill; uint32_t refill_min;   // single cut: bounce_kernel (lane refill) instead of the continuation launches; refill when >= refill_min lanes are free

@@ -112,6 +112,7 @@ struct frt_renderer {
     uint32_t ncuts = 2, cuts[kMaxCuts] = {3, 4, 0, 0};   // measured best on the Cornell Box
     uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state, or null
     bool wg_park = true;                   // pixel kernels reserve queue slots once per workgroup (FRT_WG_PARK=0: once per wave, experiment knob)
+    bool vote = false;                     // traced kernels with the voting BVH walk (set from the size of the scene's quad tree, upload_scene)
     bool wavefront = false;                // ray-level wavefront (FRT_WAVEFRONT=1): per bounce depth a trace launch and a shade launch
     uint32_t* d_wf_words[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint32_t* d_wf_items[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     uint32_t* d_wf_hits[2] = {nullptr, nullptr}; uint32_t* d_wf_counts = nullptr;   // per stage: records x 2, item lists x 2, hit buffer; 2 x 96 counters
@@ -170,11 +171,16 @@ static int upload(frt_renderer* r, const std::vector<T>& v, const D** out) {
     return FRT_OK;
 }
 
+static const size_t kVoteMinQuadNodes = 16384;      // (2 MiB of quad nodes)
 static int upload_scene(frt_renderer* r, const SceneBuilder& b) {
     SceneView& sv = r->sv;
     int rc;
     if ((rc = upload(r, b.pair_nodes, &sv.nodes))) return rc;
     if ((rc = upload(r, b.quad_nodes, &sv.nodes4))) return rc;
+    // Which walk the traced kernels use (frt_trace.hpp: trace4<ANY, VOTE>). The voting loop pays where walks are long — measured per 4K / 1080p
+    // frame: 74k quad nodes (246k triangles) 24.2 -> 21.9 ms, 25k (82k triangles) 3.46 -> 3.39 ms — and costs its own instructions where they are
+    // short: 9.5k quad nodes (32k triangles) 1.35 -> 1.39 ms, 390 (the Cornell Box) 1.61 -> 1.62 ms.
+    r->vote = b.quad_nodes.size() >= kVoteMinQuadNodes;
     if ((rc = upload(r, b.tri_slots, &sv.tris))) return rc;
     if ((rc = upload(r, b.qnode_a, &sv.qnode_a))) return rc;
     if ((rc = upload(r, b.qnode_b, &sv.qnode_b))) return rc;
@@ -700,6 +706,7 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
 static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, TraceLaunch& L, int work_slot = 0) {
     memset(&L, 0, sizeof(L));
     L.wg_park = r->wg_park;
+    L.vote = r->vote;
     L.refill = r->refill; L.refill_min = r->refill_min; L.stream = r->stream_mode; L.shade_min = r->shade_min; L.slice = r->stream_slice;
     L.resident = r->resident; L.res_nodes = r->res_nodes; L.res_tris = r->res_tris; L.num_cus = r->num_cus; L.res_batch = r->res_batch;
     L.work = r->d_work + ((size_t)(stage - 1) * kWorkSlots + (size_t)work_slot) * 2;

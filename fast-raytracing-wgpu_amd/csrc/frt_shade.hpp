@@ -65,21 +65,21 @@ struct PathCtx {
 #ifndef FRT_DBG_TWICE
 #define FRT_DBG_TWICE 0
 #endif
-    FRT_HD void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) {
-        n_closest++;
+    template <bool ANY, bool VOTE>
+    FRT_HD void walk(f3 o, f3 d, float tmin, float tmax, HitRec& h) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (FRT_DBG_TWICE & 1) { HitRec h2; f3 o2 = o; asm volatile("" : "+v"(o2.x)); trace4<false>(sc, o2, d, tmin, tmax, stk, stride, h2); asm volatile("" :: "v"(h2.t), "v"(h2.tri)); }
+        if (FRT_DBG_TWICE & (ANY ? 2 : 1)) { HitRec h2; f3 o2 = o; asm volatile("" : "+v"(o2.x)); trace4<ANY, VOTE>(sc, o2, d, tmin, tmax, stk, stride, h2); asm volatile("" :: "v"(h2.t), "v"(h2.tri)); }
 #endif
-        trace4<false>(sc, o, d, tmin, tmax, stk, stride, h);
+        trace4<ANY, VOTE>(sc, o, d, tmin, tmax, stk, stride, h);
     }
-    FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) {
-        HitRec h; n_any++;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (FRT_DBG_TWICE & 2) { HitRec h2; f3 o2 = o; asm volatile("" : "+v"(o2.x)); trace4<true>(sc, o2, d, tmin, tmax, stk, stride, h2); asm volatile("" :: "v"(h2.tri)); }
-#endif
-        trace4<true>(sc, o, d, tmin, tmax, stk, stride, h);
-        return h.tri != 0xFFFFFFFFu;
-    }
+    FRT_HD void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) { n_closest++; walk<false, false>(o, d, tmin, tmax, h); }
+    FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) { HitRec h; n_any++; walk<true, false>(o, d, tmin, tmax, h); return h.tri != 0xFFFFFFFFu; }
+};
+// The same context with the voting walk (frt_trace.hpp: trace4<ANY, VOTE = true>): what the traced kernels of scenes with a deep tree run.
+struct VotePathCtx : PathCtx {
+    FRT_HD VotePathCtx(const SceneView& s, const FrameView& f, uint32_t* st, uint32_t sd) : PathCtx(s, f, st, sd) {}
+    FRT_HD void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) { n_closest++; walk<false, true>(o, d, tmin, tmax, h); }
+    FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) { HitRec h; n_any++; walk<true, true>(o, d, tmin, tmax, h); return h.tri != 0xFFFFFFFFu; }
 };
 
 FRT_HD float rand_lcg(uint32_t& state) {   // restir.wgsl:781-786

@@ -210,7 +210,23 @@ FRT_HD void slab4(const char* n, uint32_t sx, uint32_t sy, uint32_t sz, f3 inv, 
         h[c] = tn <= tf;
     }
 }
-template <bool ANY>
+// VOTE: the node loop ends when the wave VOTES for a leaf step instead of when its last lane has reached a leaf. A lane's own sequence of node and
+// leaf steps is fixed by its ray; the wave executes a common supersequence of its lanes' sequences, and "while-while" (node steps until no lane holds
+// a node) is one heuristic for building it: every lane that has reached a leaf waits for the slowest node walker of the round. With VOTE every trip
+// of the node loop counts the lanes that wait for a node step and those that wait for a leaf step (two ballots) and leaves for a leaf step as soon as
+// the latter are the majority; lanes still holding a node sit that leaf step out. Same hits (hit semantics above do not depend on the order of the
+// steps). Pays on DEEP trees, where walks are long and their phases drift apart, and costs a little on shallow ones — its own instructions against
+// the steps it saves: 246k-triangle colonnade 24.2 -> 21.9 ms per 4K frame, 82k-triangle blob 3.46 -> 3.39 ms, 32k-triangle ReSTIR scene 1.35 ->
+// 1.39 ms, Cornell Box 1.61 -> 1.62 ms (profiles/r3_experiments/traversal_in_situ.md). The renderer picks the kernels by the size of the scene's
+// quad tree (frt_renderer.hip: kVoteMinQuadNodes). On the host (tests/hostcheck) a "wave" is one lane: the loop degenerates to the lane's own sequence.
+FRT_HD uint32_t wave_count(bool b) {      // lanes of the wave for which b holds
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(__ballot(b));
+#else
+    return b ? 1u : 0u;
+#endif
+}
+template <bool ANY, bool VOTE = false>
 FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint32_t* stk, uint32_t stride, HitRec& hit) {
     hit.t = tmax; hit.tri = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f; hit.inst = 0u; hit.front = false;
     float best_det = 0.0f;
@@ -221,8 +237,17 @@ FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint
     const float kFar = 3.0e38f;
     uint32_t* top = stk;      // next free stack entry (entries are `stride` words apart)
     uint32_t cur = 0u;   // quad node 0 is the root
+    // node loop goes on: this lane holds a node (while-while) / the wave's vote says "node step" (VOTE; wave-uniform)
+    auto node_phase = [&]() -> bool {
+        const bool at_node = !(cur & 0x80000000u);
+        if (!VOTE) return at_node;
+        // (a lane that is done has left the outer loop, or holds kDone until this loop ends: it waits for neither step)
+        const uint32_t nn = wave_count(at_node), nl = wave_count(!at_node && cur != kDone);
+        return nn != 0u && nn >= nl;
+    };
     for (;;) {
-        while (!(cur & 0x80000000u)) {
+        while (node_phase()) {
+            if (VOTE && (cur & 0x80000000u)) continue;      // this lane holds a leaf (or is done): it sits the node step out
             const uint32_t noff = cur << 7;
             const char* nb = reinterpret_cast<const char*>(sc.nodes4);
             const float4 rf = *reinterpret_cast<const float4*>(nb + (noff + 96u));
@@ -245,6 +270,7 @@ FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint
             else { top -= stride; cur = *top; }
         }
         if (cur == kDone) break;
+        if (VOTE && !(cur & 0x80000000u)) continue;      // this lane still holds a node: it sits the leaf step out
         uint32_t first = cur & 0x00FFFFFFu, count = (cur >> 24) & 0x7Fu;
         // leaves hold one or two triangles (frt_bvh.cpp; up to four under FRT_BVH_LEAF): the first two are tested in line, without a loop
         auto test = [&](uint32_t slot) -> bool {

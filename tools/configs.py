@@ -29,12 +29,17 @@ def run(name, scene, W, H, depth, nlights, frames=40, warm=8):
     del r
 
 
-cornell = frt.scenes.create_cornell_box()
-run("configs[1] Cornell 1080p d8", cornell, 1920, 1080, 8, 2)
-run("configs[2] Cornell 2160p d8 (one GPU)", cornell, 3840, 2160, 8, 2)
-restir = frt.scenes.create_restir_scene()
-run("ReSTIR 100-light scene 1080p d8", restir, 1920, 1080, 8, restir.counts()["lights"])
-fb, _ = _scenes.bumpy_sphere_in_box(frt, orc)
-run("configs[3] stand-in: 82k-triangle blob in the box 1080p d8", fb, 1920, 1080, 8, 1)
-fb, _ = _scenes.colonnade(frt, orc)
-run("configs[4] stand-in: 250k-triangle colonnade 2160p d16 (one GPU)", fb, 3840, 2160, 16, 1, frames=24)
+only = set(sys.argv[1:])      # e.g. `configs.py 3 4`: those workloads only ("r" = the ReSTIR scene)
+if not only or "1" in only or "2" in only:
+    cornell = frt.scenes.create_cornell_box()
+    if not only or "1" in only: run("configs[1] Cornell 1080p d8", cornell, 1920, 1080, 8, 2)
+    if not only or "2" in only: run("configs[2] Cornell 2160p d8 (one GPU)", cornell, 3840, 2160, 8, 2)
+if not only or "r" in only:
+    restir = frt.scenes.create_restir_scene()
+    run("ReSTIR 100-light scene 1080p d8", restir, 1920, 1080, 8, restir.counts()["lights"])
+if not only or "3" in only:
+    fb, _ = _scenes.bumpy_sphere_in_box(frt, orc)
+    run("configs[3] stand-in: 82k-triangle blob in the box 1080p d8", fb, 1920, 1080, 8, 1)
+if not only or "4" in only:
+    fb, _ = _scenes.colonnade(frt, orc)
+    run("configs[4] stand-in: 250k-triangle colonnade 2160p d16 (one GPU)", fb, 3840, 2160, 16, 1, frames=24)
