@@ -191,6 +191,13 @@ __global__ void __launch_bounds__(kBlock, FRT_WAVES) continue_kernel(SceneView s
     uint32_t* const s_cnt = &s_stack[kMiscRow * THREADS];
     const uint32_t filled = *qin.count;
     const uint32_t n = filled < qin.capacity ? filled : qin.capacity;
+    // The launch that parked these paths ran out of slots (its counter ran past the capacity; the surplus paths were finished in place): tell the
+    // host through the mapped flag whose address sits behind the overflow counter (frt_mono.hpp: ContQueue). One thread per launch, here where
+    // few registers are live — in the parking code the 64-bit address cost the traced kernels two VGPRs (112 -> 114, +1.5 % per frame).
+    if (blockIdx.x == 0u && threadIdx.x == 0u && filled > qin.capacity && qin.overflow) {
+        uint32_t* const seen = *reinterpret_cast<uint32_t* const*>(qin.overflow + 2);
+        if (seen) *reinterpret_cast<volatile uint32_t*>(seen) = 1u;
+    }
     if (blockIdx.x * (uint32_t)THREADS >= n) return;   // uniform per workgroup
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();

@@ -383,7 +383,11 @@ FRT_HD void path_loop_split(Ctx& c, LoopState& s, uint32_t depth_begin, uint32_t
 // counted in `overflow`; readers use min(*count, capacity) slots.
 // nsub > 1: the queue is cut into nsub regions of capacity / nsub slots, each with its own counter (count[0 .. nsub)): tens of thousands of
 // atomics on ONE address cost ~13 ns each on this chip (measured: 8,192 waves taking one ticket each = 120 us), eight addresses run side by side.
+// The two words behind *overflow + 2 hold a pointer (or null) to a word of host memory mapped into the device; the continuation launch that finds
+// its input queue overfull stores 1 there, so that the host notices at its next call — without a copy, a synchronisation or a stats query —
+// that the queues want growing (frt_kernels.hip: continue_kernel; frt_renderer.hip: grow_queues_if_overflowed).
 struct ContQueue { uint32_t* words; uint32_t* count; uint32_t capacity; uint32_t* overflow; uint32_t nsub; };
+static constexpr int kOverflowBlockWords = 4;      // per traced stage: {count, pad, pointer to the mapped flag (2 words)}
 static constexpr int kContWordsPath = 22, kContWordsSpatial = 25;
 
 FRT_HD void cont_store(const ContQueue& q, uint32_t slot, uint32_t pix, uint32_t rng, bool owned, const LoopState& s, const ReservoirView* r) {

@@ -108,6 +108,7 @@ struct frt_renderer {
     long cont_grid = -1;                   // FRT_CONT_GRID: slots the spatial continuation grids cover at least (-1: half the stage's pixels)
     bool qcap_fixed = false;               // capacity given by the caller: never grown
     uint32_t* d_qcount = nullptr;          // [stage 1|2][launch parity 0|1][kMaxCuts + 1] counters, then [stage] overflow counters
+    uint32_t* h_qseen = nullptr; uint32_t* d_qseen = nullptr;   // one word of mapped host memory: set by a wave that found its queue full (ContQueue::seen)
     uint32_t qparity[2] = {0, 0};
     uint32_t ncuts = 2, cuts[kMaxCuts] = {3, 4, 0, 0};   // measured best on the Cornell Box
     uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state, or null
@@ -477,6 +478,7 @@ void frt_renderer_destroy(frt_renderer* r) {
     if (r->d_counters) (void)hipFree(r->d_counters);
     free_queues(r);
     if (r->d_qcount) (void)hipFree(r->d_qcount);
+    if (r->h_qseen) (void)hipHostFree(r->h_qseen);
     if (r->d_wf_counts) (void)hipFree(r->d_wf_counts);
     if (r->d_tiles) (void)hipFree(r->d_tiles);
     if (r->d_work) (void)hipFree(r->d_work);
@@ -487,10 +489,20 @@ void frt_renderer_destroy(frt_renderer* r) {
 static const size_t kWfCounterWords = 1024;                        // per stage: record counts per pass and region, item counts at +512
 static const int kWorkSlots = 3 + kMaxCuts;                       // pixel launch (interior / whole), the two edge launches, one per continuation launch
 static const size_t kWorkWords = 2 * kWorkSlots * 2;               // [stage][slot]{next, ticket}
-static const size_t kQcountWords = 2 * 2 * (kMaxCuts + 1) + 2;   // [stage][parity][segment] counters + [stage] overflow counters
+static const size_t kQoverflowAt = 2 * 2 * (kMaxCuts + 1);      // (even: the pointers in the overflow blocks are 8-byte aligned)
+static const size_t kQcountWords = kQoverflowAt + 2 * kOverflowBlockWords;   // [stage][parity][segment] counters + [stage] overflow blocks {count, pad, pointer to the mapped flag}
 static bool stage_is_cut(const frt_renderer* r) { return r->ncuts > 0 && r->cuts[0] < r->max_depth && !(r->flags & FRT_FLAG_COMPACTION); }
 
 // Continuation queues for `cap` parked paths per segment. T-trace parks 22 words per path, spatial 30 (its merged reservoir rides along).
+// Zeroes the queue counters and (re)writes the overflow blocks' pointers to the mapped flag (ContQueue, frt_mono.hpp). On r->stream.
+static int clear_queue_counters(frt_renderer* r) {
+    HIP_TRY(hipMemsetAsync(r->d_qcount, 0, kQcountWords * sizeof(uint32_t), r->stream));
+    if (r->d_qseen)
+        for (int st = 0; st < 2; ++st)
+            HIP_TRY(hipMemcpyAsync(r->d_qcount + kQoverflowAt + (size_t)st * kOverflowBlockWords + 2, &r->d_qseen, sizeof(uint32_t*), hipMemcpyHostToDevice, r->stream));
+    if (r->h_qseen) *reinterpret_cast<volatile uint32_t*>(r->h_qseen) = 0u;
+    return FRT_OK;
+}
 static int alloc_queues(frt_renderer* r, uint32_t cap) {
     free_queues(r);
     r->qcap = cap;
@@ -624,7 +636,12 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         HIP_TRY(hipMalloc((void**)&r->d_wf_counts, 2 * kWfCounterWords * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(r->d_wf_counts, 0, 2 * kWfCounterWords * sizeof(uint32_t), r->stream));
         HIP_TRY(hipMalloc((void**)&r->d_qcount, kQcountWords * sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(r->d_qcount, 0, kQcountWords * sizeof(uint32_t), r->stream));
+        // (no mapped host memory -> no flag: the queues are then grown by frt_renderer_stats alone, as before)
+        if (hipHostMalloc((void**)&r->h_qseen, sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            *r->h_qseen = 0u;
+            if (hipHostGetDevicePointer((void**)&r->d_qseen, r->h_qseen, 0) != hipSuccess) { (void)hipHostFree(r->h_qseen); r->h_qseen = nullptr; r->d_qseen = nullptr; }
+        } else { r->h_qseen = nullptr; (void)hipGetLastError(); }
+        { int rc_ = clear_queue_counters(r); if (rc_) return rc_; }
 #if FRT_EXPERIMENTS
         // Sweep direction of the tile rows (experiments/frt_experiment_kernels.hpp: TileOrder; resident pixel kernels only): FRT_TILE_ORDER=1
         if (const char* e = getenv("FRT_TILE_ORDER"); e && atoi(e) != 0) {
@@ -725,7 +742,7 @@ static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, Tr
     // dispatched the main stream keeps its turn at the dispatcher beside the next frame's T-trace pixel kernel (profiles/r2_schedule_notes.md).
     L.grid_min_slots = (stage == 2 && r->pipeline()) ? (uint32_t)std::min<uint64_t>(r->qcap_max, (uint64_t)r->W * (r->re - r->rb) / 2u) : 0u;
     if (r->cont_grid >= 0) L.grid_min_slots = (uint32_t)r->cont_grid;   // (FRT_CONT_GRID: experiment knob, read at creation)
-    L.overflow = r->d_qcount + 2 * 2 * (kMaxCuts + 1) + (stage - 1);
+    L.overflow = r->d_qcount + kQoverflowAt + (size_t)(stage - 1) * kOverflowBlockWords;
     L.tile_state = (with_tile_state && r->d_tiles) ? r->d_tiles + (size_t)(stage - 1) * kTileStateWords : nullptr;
     if (r->wavefront && cut) {
         L.wavefront = true;
@@ -794,7 +811,43 @@ static GSlots alloc_g(frt_renderer* r, uint32_t frame_count) {
     return gs;
 }
 
+// Queues that overflowed since the last look (paths were finished in place, nothing was lost) are doubled. The device must be idle (sync_all):
+// called from frt_renderer_stats, and from the first phase of a frame when a wave has raised the mapped flag (ContQueue::seen), so that a host
+// that never asks for statistics still gets queues that fit its scene — the default shares are the Cornell Box's.
+static int grow_queues_if_overflowed(frt_renderer* r) {
+    if (!r->d_qcount) return FRT_OK;
+    uint32_t blk[2 * kOverflowBlockWords] = {0};
+    HIP_TRY(hipMemcpy(blk, r->d_qcount + kQoverflowAt, sizeof(blk), hipMemcpyDeviceToHost));
+    const uint32_t ov[2] = {blk[0], blk[kOverflowBlockWords]};
+#if FRT_EXPERIMENTS
+    if (getenv("FRT_DEBUG_QUEUES")) {   // (debug: the queue counters of the last launches, [stage][parity][segment])
+        uint32_t qc[kQcountWords];
+        HIP_TRY(hipMemcpy(qc, r->d_qcount, sizeof(qc), hipMemcpyDeviceToHost));
+        fprintf(stderr, "queues slots T %u %u S %u %u:", r->qslots[0][0], r->qslots[0][1], r->qslots[1][0], r->qslots[1][1]);
+        for (size_t i = 0; i < kQcountWords; ++i) fprintf(stderr, " %u", qc[i]);
+        fprintf(stderr, "\n");
+    }
+#endif
+    if (r->h_qseen) *reinterpret_cast<volatile uint32_t*>(r->h_qseen) = 0u;
+    if (ov[0] || ov[1]) {
+        r->stats.queue_overflow += (uint64_t)ov[0] + ov[1];
+        for (int st = 0; st < 2; ++st) HIP_TRY(hipMemset(r->d_qcount + kQoverflowAt + (size_t)st * kOverflowBlockWords, 0, sizeof(uint32_t)));
+        if (!r->qcap_fixed && r->qcap < r->qcap_max) {
+            const int rc = alloc_queues(r, (uint32_t)std::min<uint64_t>(r->qcap_max, (uint64_t)r->qcap * 2u));
+            if (rc) return rc;
+        }
+    }
+    return FRT_OK;
+}
 static int open_frame(frt_renderer* r, const frt_camera_uniform* cam) {
+    // a wave of an earlier frame found its continuation queue full: grow the queues now, between two frames (one synchronisation, at most twice in
+    // a renderer's life: 0.25 -> 0.5 -> 1 slot per pixel)
+    if (r->h_qseen && *reinterpret_cast<volatile uint32_t*>(r->h_qseen) != 0u && !r->qcap_fixed && r->qcap < r->qcap_max) {
+        int rc = sync_all(r);
+        if (rc) return rc;
+        rc = grow_queues_if_overflowed(r);
+        if (rc) return rc;
+    }
     r->frame_open = true;
     r->cur_cam = *cam;
     r->g_done = r->tt_done = r->tm_done = r->s_started = r->s_inner_done = r->s_edge_done = false;
@@ -1050,7 +1103,7 @@ int frt_renderer_clear(frt_renderer* r) {
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));
     if (r->extras) HIP_TRY(hipMemsetAsync(r->extras, 0, r->extras_bytes, r->stream));
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, C_COUNT * sizeof(unsigned long long), r->stream));
-    HIP_TRY(hipMemsetAsync(r->d_qcount, 0, kQcountWords * sizeof(uint32_t), r->stream));
+    { int rc_ = clear_queue_counters(r); if (rc_) return rc_; }
     HIP_TRY(hipMemsetAsync(r->d_work, 0, kWorkWords * sizeof(uint32_t), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     rc = init_tile_state(r);
@@ -1140,26 +1193,8 @@ int frt_renderer_stats(frt_renderer* r, frt_stats* out) {
         r->stats.rays_stage[st][0] = c[2 * st]; r->stats.rays_stage[st][1] = c[2 * st + 1];
         r->stats.rays_closest += c[2 * st]; r->stats.rays_any += c[2 * st + 1];
     }
-    // queues that overflowed since the last call (paths were finished in place, nothing was lost): grow them while the GPU is idle
-    uint32_t ov[2] = {0, 0};
-    HIP_TRY(hipMemcpy(ov, r->d_qcount + 2 * 2 * (kMaxCuts + 1), sizeof(ov), hipMemcpyDeviceToHost));
-#if FRT_EXPERIMENTS
-    if (getenv("FRT_DEBUG_QUEUES")) {   // (debug: the queue counters of the last launches, [stage][parity][segment])
-        uint32_t qc[kQcountWords];
-        HIP_TRY(hipMemcpy(qc, r->d_qcount, sizeof(qc), hipMemcpyDeviceToHost));
-        fprintf(stderr, "queues slots T %u %u S %u %u:", r->qslots[0][0], r->qslots[0][1], r->qslots[1][0], r->qslots[1][1]);
-        for (size_t i = 0; i < kQcountWords; ++i) fprintf(stderr, " %u", qc[i]);
-        fprintf(stderr, "\n");
-    }
-#endif
-    if (ov[0] || ov[1]) {
-        r->stats.queue_overflow += (uint64_t)ov[0] + ov[1];
-        HIP_TRY(hipMemset(r->d_qcount + 2 * 2 * (kMaxCuts + 1), 0, sizeof(ov)));
-        if (!r->qcap_fixed && r->qcap < r->qcap_max) {
-            rc = alloc_queues(r, (uint32_t)std::min<uint64_t>(r->qcap_max, (uint64_t)r->qcap * 2u));
-            if (rc) return rc;
-        }
-    }
+    rc = grow_queues_if_overflowed(r);
+    if (rc) return rc;
     r->stats.queue_capacity = r->qcap;
     r->stats.queue_bytes = r->qbytes;
     *out = r->stats;

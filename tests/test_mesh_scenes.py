@@ -246,3 +246,30 @@ def test_config4_sixty_four_frames(frt, orc):
     # the running mean settles: frames 33..64 move the image mean by less than frames 1..32 brought it from black
     m64, m32 = acc[..., :3].mean(), half[..., :3].mean()
     assert m64 > 0.01 and abs(m64 - m32) < 0.05 * m64, (m32, m64)
+
+
+@pytest.mark.gpu
+def test_queues_grow_by_themselves_on_a_scene_that_parks_more_paths_than_the_cornell_box(frt, orc):
+    """The continuation queues are sized from the Cornell Box's measured shares; the open hall of configs[4]'s stand-in parks more paths per
+    pixel. A wave that finds its queue full raises a flag in mapped host memory and the next frame's first phase doubles the queues — without
+    frt_renderer_stats ever being called (a host that only renders). Pixels do not depend on it (paths finish in place: checked above and in
+    test_gpu_parity.py::test_queue_overflow_*); here: the overflow stops after the first frames and the image equals a pre-grown renderer's."""
+    if frt.lib().frt_device_count() < 1:
+        pytest.fail("no HIP device")
+    fs, _ = _scenes.colonnade(frt, orc)
+    W, H, depth = 1920, 1080, 16
+    cams = [frt.CameraController().build_uniform(W / H, f, fs.num_lights) for f in range(8)]
+    r = frt.Renderer(fs, W, H, max_depth=depth, flags=frt.FLAG_PIPELINE)
+    for c in cams[:4]:
+        r.render(c); r.sync()                       # (a host that presents every frame; no stats)
+    s1 = r.stats()
+    assert s1["queue_overflow"] > 0 and s1["queue_capacity"] > W * H // 4, s1       # grew past the default 0.25 slots per pixel
+    for c in cams[4:]:
+        r.render(c); r.sync()
+    s2 = r.stats()
+    assert s2["queue_overflow"] == s1["queue_overflow"] and s2["queue_capacity"] == s1["queue_capacity"], (s1, s2)
+    big = frt.Renderer(fs, W, H, max_depth=depth, flags=frt.FLAG_PIPELINE, queue_capacity=W * H)      # never overflows
+    for c in cams: big.render(c)
+    assert big.stats()["queue_overflow"] == 0
+    assert big.read_accum().tobytes() == r.read_accum().tobytes()
+    assert (big.stats()["rays_closest"], big.stats()["rays_any"]) == (s2["rays_closest"], s2["rays_any"])
