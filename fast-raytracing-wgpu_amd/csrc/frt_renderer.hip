@@ -593,6 +593,9 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         // 1.97 at 3 and 5, 1.92 at 3 and 4; half a frame 1.41 uncut, 1.13 cut at 3, 1.09 at 3 and 4; a quarter 0.76 / 0.66 / 0.69; an
         // eighth 0.61 / 0.57 / 0.61. The second cut pays once the launch fills the chip several times over; a thin strip gets the first only.
         if ((size_t)r->W * (r->re - r->rb) < 800000u) r->ncuts = 1;
+        // deep paths (MAX_DEPTH above the reference's 8): a third cut at 6 — configs[4]'s stand-in (MAX_DEPTH 16, 3840x2160) 21.7 -> 21.3 ms with cuts at
+        // 3, 4, 6 (3, 4, 5, 7: 21.2; 3, 4, 6, 9: 21.4; 3, 6, 10: 22.0; tools/cuts_big.py)
+        else if (r->max_depth > 8u) { r->ncuts = 3; r->cuts[2] = 6u; }
         // frt_render_opts.cut_depths: ascending depths (others are skipped); all zero = the choice above; first entry 0xFFFFFFFF = never cut
         if (o && o->cut_depths[0] != 0u) {
             r->ncuts = 0;
