@@ -8,6 +8,7 @@
 // depend on the tree: DESIGN.md §3).
 #include "frt_scene.hpp"
 #include "frt_shade.hpp"
+#include "frt_bvh_opt.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -116,6 +117,8 @@ struct Builder {
 };
 } // namespace
 
+static const size_t kBvhOptMinTris = 8192;
+
 void SceneBuilder::build_bvh2() {
     bvh2.clear(); bvh2_tri_index.clear();
     bvh_depth = bvh_leaves = bvh_max_leaf = 0;
@@ -144,6 +147,9 @@ void SceneBuilder::build_bvh2() {
     bvh2_tri_index.resize(tris.size());
     for (size_t i = 0; i < tris.size(); ++i) bvh2_tri_index[i] = b.prims[i].id;
     bvh_depth = b.max_depth; bvh_leaves = b.leaves; bvh_max_leaf = b.max_leaf;
+    // Larger scenes: one pass of insertion-based optimisation over the tree just built (frt_bvh_opt.hpp: what it buys per scene size, and why small
+    // scenes are left alone). Same leaves, same triangles: pixels cannot change. Build time of the 246k-triangle scene 0.33 -> 1.1 s.
+    if (tris.size() >= kBvhOptMinTris) bvh_depth = optimize_bvh2(bvh2, bvh2_tri_index, 1, (uint32_t)kMaxBvhDepth, bvh_depth);
     if ((int)bvh_depth > kMaxBvhDepth) error = "BVH depth exceeds the traversal stack";
 }
 

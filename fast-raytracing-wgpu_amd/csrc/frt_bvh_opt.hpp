@@ -1,6 +1,8 @@
-// bvh_insertion_opt.hpp — insertion-based optimisation of the canonical BVH2 (host only, deterministic). NOT part of the product: measured with
-// tools/bvh_quality.cpp and not kept — it lowers the surface-area cost of the Cornell tree by 6 % and RAISES what a wave pays per incoherent ray by 8 %
-// (deeper tree: 14 -> 25 levels, stack need 22 -> 29), profiles/r3_experiments/traversal_in_situ.md.
+// frt_bvh_opt.hpp — insertion-based optimisation of the canonical BVH2 (host only, deterministic). Used by frt_bvh.cpp for scenes of kBvhOptMinTris
+// triangles and more, where it pays (one pass: 32k-triangle ReSTIR scene 1.336 -> 1.295 ms per frame, 82k-triangle blob 3.37 -> 3.24 ms, 246k-triangle
+// colonnade 21.2 -> 21.0 ms); on the Cornell Box it lowers the tree's surface-area cost by 6 % and RAISES what a wave pays per incoherent ray by 8 %
+// (deeper tree: 14 -> 25 levels; tools/bvh_quality.cpp, profiles/r3_experiments/traversal_in_situ.md) — measured 1.613 -> 1.618 ms: small scenes
+// keep the tree as built.
 //
 // The binned-SAH build (frt_bvh.cpp: Builder) decides every split from centroids alone and never revisits it. This pass lowers the tree's
 // surface-area cost afterwards, the way Bittner, Hapala and Havran describe ("Fast insertion-based optimization of bounding volume
@@ -10,7 +12,7 @@
 // triangles a ray hits — and therefore every pixel — is unchanged (hit semantics do not depend on the tree); only the number of
 // node steps a ray takes changes. The result is re-emitted in the canonical layout (children adjacent, after their parent, depth-first).
 #pragma once
-#include "../include/frt.h"
+#include "../../include/frt.h"
 #include <algorithm>
 #include <cstdint>
 #include <queue>

@@ -1,7 +1,7 @@
 """tools/bvh_quality — the host model of the lockstep BVH walk (profiles/r3_experiments/traversal_in_situ.md).
 
 What a ray hits must not depend on how a wave schedules its lanes' steps (while-while, voting), on idle lanes helping (a ray's root children
-dealt to several lanes), or on the tree (insertion-optimised BVH2): the model reports a checksum of the hits, and the step counts it prints are
+dealt to several lanes), or on the tree (the insertion-optimised BVH2 the product builds for larger scenes): the model reports a checksum of the hits, and the step counts it prints are
 only meaningful if those agree. Also pins the headline numbers of the notes loosely (a bounce ray: ~3.6 node steps per lane, ~11 per wave)."""
 import os
 import re

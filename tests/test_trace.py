@@ -96,6 +96,24 @@ def test_quad_tree_covers_the_scene_and_fits_the_stack(frt, hostcheck):
     q = hostcheck.quad_stats(fs); b = fs.bvh_stats()
     assert q["leaves"] == b["leaves"] and q["triangles"] == fs.get("bvh2_tri_index").size
     assert q["stack_walked"] == q["stack_need"] <= 32 and q["nodes"] < b["pair_nodes"] * 0.6 and q["children_x100"] > 300
+    # a scene large enough for the builder's insertion-optimisation pass (frt_bvh_opt.hpp; 8192 triangles and more): the re-emitted tree must be a
+    # valid canonical BVH2 — children adjacent and behind their parent, every box containing its children's, every triangle under one leaf —
+    # within the depth the traversal stack is sized for, and its quad tree must fit the stack like any other
+    big = frt.scenes.create_restir_scene()
+    nodes = big.get("bvh2_nodes"); idx = big.get("bvh2_tri_index"); bb = big.bvh_stats()
+    assert idx.size >= 8192 and bb["depth"] <= 30
+    lo = nodes[:, 0:3].view(np.float32); hi = nodes[:, 4:7].view(np.float32); left = nodes[:, 3]; cnt = nodes[:, 7]
+    inner = np.nonzero(cnt == 0)[0]
+    assert np.all(left[inner] > inner) and np.all(left[inner] + 1 < len(nodes))
+    for c in (left[inner], left[inner] + 1):
+        assert np.all(lo[inner] <= lo[c]) and np.all(hi[inner] >= hi[c])
+    kids = np.concatenate([left[inner], left[inner] + 1])
+    assert np.array_equal(np.sort(kids), np.arange(1, len(nodes)))              # every node but the root is the child of exactly one node
+    leaves = np.nonzero(cnt > 0)[0]
+    covered = np.concatenate([np.arange(left[l], left[l] + cnt[l]) for l in leaves])
+    assert np.array_equal(np.sort(covered), np.arange(idx.size)) and np.array_equal(np.sort(idx), np.arange(idx.size))
+    qb = hostcheck.quad_stats(big)
+    assert qb["stack_walked"] == qb["stack_need"] <= 32 and qb["leaves"] == bb["leaves"] and qb["triangles"] == idx.size
     # a deep, lopsided tree: triangle sizes and positions in geometric progression make the SAH peel one triangle per level
     n = 120
     pos = np.zeros((3 * n, 4), np.float32); pos[:, 3] = 1.0

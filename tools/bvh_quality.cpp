@@ -8,10 +8,10 @@
 // bounce ray, a shadow ray to a point on a light, and a second bounce — in LOCKSTEP per tile, exactly like a wave of trace4 (frt_trace.hpp): an
 // inner loop in which every lane that holds a node takes a node step until no lane holds a node, then one leaf step for the lanes that hold a
 // leaf. Reported per ray kind: node steps and triangle tests per lane-ray, and node steps / leaf steps per WAVE-ray (what the SIMD executes).
-// With [insertion passes] > 0 the BVH2 first goes through the insertion-based optimisation of tools/bvh_insertion_opt.hpp so that the
+// With [insertion passes] > 0 the BVH2 first goes through the insertion-based optimisation of csrc/frt_bvh_opt.hpp so that the
 // two trees can be compared before anything runs on the GPU.
 #include "frt.h"
-#include "bvh_insertion_opt.hpp"
+#include "../fast-raytracing-wgpu_amd/csrc/frt_bvh_opt.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
