@@ -172,15 +172,19 @@ static int upload(frt_renderer* r, const std::vector<T>& v, const D** out) {
     return FRT_OK;
 }
 
-static const size_t kVoteMinQuadNodes = 16384;      // (2 MiB of quad nodes)
+#ifndef FRT_VOTE_MIN_NODES
+#define FRT_VOTE_MIN_NODES 32768      // (4 MiB of quad nodes; A/B builds: 0 = every scene votes, a huge value = none does)
+#endif
+static const size_t kVoteMinQuadNodes = FRT_VOTE_MIN_NODES;
 static int upload_scene(frt_renderer* r, const SceneBuilder& b) {
     SceneView& sv = r->sv;
     int rc;
     if ((rc = upload(r, b.pair_nodes, &sv.nodes))) return rc;
     if ((rc = upload(r, b.quad_nodes, &sv.nodes4))) return rc;
-    // Which walk the traced kernels use (frt_trace.hpp: trace4<ANY, VOTE>). The voting loop pays where walks are long — measured per 4K / 1080p
-    // frame: 74k quad nodes (246k triangles) 24.2 -> 21.9 ms, 25k (82k triangles) 3.46 -> 3.39 ms — and costs its own instructions where they are
-    // short: 9.5k quad nodes (32k triangles) 1.35 -> 1.39 ms, 390 (the Cornell Box) 1.61 -> 1.62 ms.
+    // Which walk the traced kernels use (frt_trace.hpp: trace4<ANY, VOTE>). The voting loop pays where walks are long and costs its own instructions
+    // where they are short. Per frame, never / always voting, with the leaf step that fetches both triangles together (before it the 25k-node scene
+    // still gained 2 %): 74k quad nodes (246k triangles, 4K, 16 bounces) 20.98 / 19.79 ms; 25k (82k triangles) 2.948 / 2.987 ms; 9.5k (32k triangles)
+    // 1.279 / 1.340 ms; 390 (the Cornell Box) 1.565 / 1.611 ms.
     r->vote = b.quad_nodes.size() >= kVoteMinQuadNodes;
     if ((rc = upload(r, b.tri_slots, &sv.tris))) return rc;
     if ((rc = upload(r, b.qnode_a, &sv.qnode_a))) return rc;

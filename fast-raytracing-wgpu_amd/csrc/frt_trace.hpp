@@ -216,8 +216,8 @@ FRT_HD void slab4(const char* n, uint32_t sx, uint32_t sy, uint32_t sz, f3 inv, 
 // of the node loop counts the lanes that wait for a node step and those that wait for a leaf step (two ballots) and leaves for a leaf step as soon as
 // the latter are the majority; lanes still holding a node sit that leaf step out. Same hits (hit semantics above do not depend on the order of the
 // steps). Pays on DEEP trees, where walks are long and their phases drift apart, and costs a little on shallow ones — its own instructions against
-// the steps it saves: 246k-triangle colonnade 24.2 -> 21.9 ms per 4K frame, 82k-triangle blob 3.46 -> 3.39 ms, 32k-triangle ReSTIR scene 1.35 ->
-// 1.39 ms, Cornell Box 1.61 -> 1.62 ms (profiles/r3_experiments/traversal_in_situ.md). The renderer picks the kernels by the size of the scene's
+// the steps it saves: 246k-triangle colonnade 21.0 -> 19.8 ms per 4K frame, 82k-triangle blob 2.95 -> 2.99 ms, 32k-triangle ReSTIR scene 1.28 ->
+// 1.34 ms, Cornell Box 1.57 -> 1.61 ms (profiles/r3_experiments/traversal_in_situ.md). The renderer picks the kernels by the size of the scene's
 // quad tree (frt_renderer.hip: kVoteMinQuadNodes). On the host (tests/hostcheck) a "wave" is one lane: the loop degenerates to the lane's own sequence.
 FRT_HD uint32_t wave_count(bool b) {      // lanes of the wave for which b holds
 #if defined(__HIP_DEVICE_COMPILE__)
