@@ -43,15 +43,27 @@ __device__ __forceinline__ void flush_ray_counters(const FrameView& fv, uint32_t
     }
 }
 
+// The top of the quad tree — nodes 0 .. kLdsTopNodes - 1: the root and, numbered breadth-first, its children — copied into the workgroup's LDS, in the
+// row of the stack array that no stack entry reaches (behind the shared words): the first two node steps of every walk read it there (frt_trace.hpp:
+// trace4). Call before the workgroup's first barrier; null for a tree too small to have those nodes.
+__device__ __forceinline__ const uint32_t* stage_top_nodes(const SceneView& sc, uint32_t* s_cnt) {
+    uint32_t* const s_top = s_cnt + 32;      // (128-byte aligned)
+    if (sc.num_nodes4 < (uint32_t)kLdsTopNodes) return nullptr;
+    if (threadIdx.x < (uint32_t)kLdsTopNodes * 32u) s_top[threadIdx.x] = reinterpret_cast<const uint32_t*>(sc.nodes4)[threadIdx.x];
+    return s_top;
+}
+
 // G-buffer: one primary ray per pixel, coherent within the 8x8 tile (lane utilisation 96 %): plain thread-per-pixel launch.
 __global__ void __launch_bounds__(kBlock) gbuffer_kernel(SceneView sc, FrameView fv) {
     __shared__ uint32_t s_stack[kStackDepth * kBlock];
     uint32_t* const s_cnt = &s_stack[kMiscRow * kBlock];
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    const uint32_t* const s_top = stage_top_nodes(sc, s_cnt);
     __syncthreads();
     uint32_t px, py;
     bool active = tile_pixel(fv, px, py);
     PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
+    c.lds_top = s_top;
     if (active) gbuffer_pixel(c, px, py);
     bool counted = active && py >= fv.own_y0 && py < fv.own_y1;
     flush_ray_counters(fv, counted ? c.n_closest : 0u, counted ? c.n_any : 0u, s_cnt);
@@ -140,6 +152,7 @@ __global__ void __launch_bounds__(kBlock, FRT_WAVES) pixel_kernel(SceneView sc, 
     uint32_t* const s_cnt = &s_stack[kMiscRow * THREADS];
     uint32_t* const s_tmp = s_cnt + 8;
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    const uint32_t* const s_top = stage_top_nodes(sc, s_cnt);
     __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
     // the queue counters this stage's NEXT launch will use (the other set of the pair) are cleared here instead of by a memset
@@ -147,6 +160,7 @@ __global__ void __launch_bounds__(kBlock, FRT_WAVES) pixel_kernel(SceneView sc, 
     uint32_t px, py;
     const bool active = tile_pixel(fv, px, py);      // tile rows top to bottom (a sweep from the expensive end of the image was measured: 1-2 % slower, profiles/r2_experiments)
     typename CtxOf<VOTE>::type c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
+    c.lds_top = s_top;
     const uint32_t pix = py * fv.W + px;
     const bool counted = active && py >= fv.own_y0 && py < fv.own_y1;
     LoopState s;
@@ -200,9 +214,11 @@ __global__ void __launch_bounds__(kBlock, FRT_WAVES) continue_kernel(SceneView s
     }
     if (blockIdx.x * (uint32_t)THREADS >= n) return;   // uniform per workgroup
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    const uint32_t* const s_top = stage_top_nodes(sc, s_cnt);
     __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
     typename CtxOf<VOTE>::type c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
+    c.lds_top = s_top;
     uint32_t cnt_closest = 0u, cnt_any = 0u;
     // stride loop: one trip with the grid of launch_trace_continuations; uniform per workgroup for any grid
     for (uint32_t base = blockIdx.x * (uint32_t)THREADS; base < n; base += gridDim.x * (uint32_t)THREADS) {

@@ -191,6 +191,7 @@ static int upload_scene(frt_renderer* r, const SceneBuilder& b) {
     if ((rc = upload(r, b.qnode_b, &sv.qnode_b))) return rc;
     for (int a = 0; a < 3; ++a) { sv.qmin[a] = b.qmin[a]; sv.qstep[a] = b.qstep[a]; }
     sv.bvh_depth = b.bvh_depth;
+    sv.num_nodes4 = (uint32_t)b.quad_nodes.size();
     if ((rc = upload(r, b.shade_tris, &sv.shade_tris))) return rc;
     if ((rc = upload(r, b.instances_dev, &sv.instances))) return rc;
     if ((rc = upload(r, b.mesh_infos, &sv.mesh_infos))) return rc;

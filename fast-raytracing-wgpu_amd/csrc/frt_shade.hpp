@@ -52,6 +52,7 @@ struct PathCtx {
     const SceneView& sc;
     const FrameView& fv;
     uint32_t* stk; uint32_t stride;
+    const uint32_t* lds_top = nullptr;   // the workgroup's LDS copy of quad nodes 0 .. 4 (frt_kernels.hip: stage_top_nodes), or null: trace4 then reads them like any node
     uint32_t rng;               // var<private> rng_seed, restir.wgsl:130
     uint32_t n_closest, n_any;  // rays issued by this lane
     FRT_HD PathCtx(const SceneView& s, const FrameView& f, uint32_t* st, uint32_t sd) : sc(s), fv(f), stk(st), stride(sd), rng(0), n_closest(0), n_any(0) {}
@@ -68,9 +69,9 @@ struct PathCtx {
     template <bool ANY, bool VOTE>
     FRT_HD void walk(f3 o, f3 d, float tmin, float tmax, HitRec& h) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (FRT_DBG_TWICE & (ANY ? 2 : 1)) { HitRec h2; f3 o2 = o; asm volatile("" : "+v"(o2.x)); trace4<ANY, VOTE>(sc, o2, d, tmin, tmax, stk, stride, h2); asm volatile("" :: "v"(h2.t), "v"(h2.tri)); }
+        if (FRT_DBG_TWICE & (ANY ? 2 : 1)) { HitRec h2; f3 o2 = o; asm volatile("" : "+v"(o2.x)); trace4<ANY, VOTE>(sc, o2, d, tmin, tmax, stk, stride, h2, lds_top); asm volatile("" :: "v"(h2.t), "v"(h2.tri)); }
 #endif
-        trace4<ANY, VOTE>(sc, o, d, tmin, tmax, stk, stride, h);
+        trace4<ANY, VOTE>(sc, o, d, tmin, tmax, stk, stride, h, lds_top);
     }
     FRT_HD void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) { n_closest++; walk<false, false>(o, d, tmin, tmax, h); }
     FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) { HitRec h; n_any++; walk<true, false>(o, d, tmin, tmax, h); return h.tri != 0xFFFFFFFFu; }
@@ -355,7 +356,7 @@ FRT_HD void gbuffer_pixel(PathCtx& c, uint32_t px, uint32_t py) {
     f3 direction = normalize(xyz(target) / target.w - origin);
     HitRec h;
     c.n_closest++;
-    trace4<false>(sc, origin, direction, 0.001f, 1000.0f, c.stk, c.stride, h);
+    trace4<false>(sc, origin, direction, 0.001f, 1000.0f, c.stk, c.stride, h, c.lds_top);
     if (h.tri == 0xFFFFFFFFu) {
         fv.gpos[pix] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
         fv.gnormal[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

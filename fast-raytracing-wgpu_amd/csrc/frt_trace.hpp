@@ -13,6 +13,7 @@
 
 namespace frt {
 
+static const int kLdsTopNodes = 5;      // quad nodes 0 .. 4 (the root and, numbered breadth-first, its children) are copied into a workgroup's LDS (trace4)
 #ifndef FRT_STACK
 #define FRT_STACK 32      // (A/B builds only: a shallower LDS stack for scenes whose quad tree needs no more)
 #endif
@@ -46,6 +47,7 @@ struct SceneView {
     const uint4* qnode_a; const uint4* qnode_b;
     float qmin[3], qstep[3];
     uint32_t bvh_depth;
+    uint32_t num_nodes4;        // quad nodes (in the padding before the pointer below)
     const float4* nodes4;       // quad nodes, 8 x float4 each (frt_bvh.cpp: build_quad_nodes): what the default kernels walk (trace4)
 };
 
@@ -227,7 +229,7 @@ FRT_HD uint32_t wave_count(bool b) {      // lanes of the wave for which b holds
 #endif
 }
 template <bool ANY, bool VOTE = false>
-FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint32_t* stk, uint32_t stride, HitRec& hit) {
+FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint32_t* stk, uint32_t stride, HitRec& hit, const uint32_t* lds_top = nullptr) {
     hit.t = tmax; hit.tri = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f; hit.inst = 0u; hit.front = false;
     float best_det = 0.0f;
     f3 inv = mk3(prune_rcp(d.x), prune_rcp(d.y), prune_rcp(d.z));
@@ -245,6 +247,34 @@ FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint
         const uint32_t nn = wave_count(at_node), nl = wave_count(!at_node && cur != kDone);
         return nn != 0u && nn >= nl;
     };
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The first steps of every walk — the root, then one of its children (quad nodes 1 .. 4: the tree is numbered breadth-first) — read their node from
+    // the workgroup's LDS copy of nodes 0 .. 4 while EVERY lane of the wave is still up there (wave-uniform test): two of a walk's ten node steps
+    // leave the L1 alone and see the LDS's latency instead: Cornell Box 1.560 -> 1.537 ms per frame (8 more VGPRs, still four waves per SIMD).
+    if (lds_top) {
+        while (__ballot(cur >= (uint32_t)kLdsTopNodes) == 0ull) {
+            const uint32_t noff = cur << 7;
+            const char* nb = reinterpret_cast<const char*>(lds_top);
+            const float4 rf = *reinterpret_cast<const float4*>(nb + (noff + 96u));
+            float t[4]; bool h[4];
+            slab4(nb, noff | sx, noff | sy, noff | sz, inv, oinv, tmin, ANY ? tmax : hit.t, t, h);
+            uint32_t r[4] = {f2u(rf.x), f2u(rf.y), f2u(rf.z), f2u(rf.w)};
+            float k[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) k[c] = h[c] ? t[c] : kFar;
+#define FRT_CE(a, b) { const bool s_ = k[b] < k[a]; const float ka_ = s_ ? k[b] : k[a], kb_ = s_ ? k[a] : k[b]; \
+                       const uint32_t ra_ = s_ ? r[b] : r[a], rb_ = s_ ? r[a] : r[b]; k[a] = ka_; k[b] = kb_; r[a] = ra_; r[b] = rb_; }
+            FRT_CE(0, 1) FRT_CE(2, 3) FRT_CE(0, 2) FRT_CE(1, 3) FRT_CE(1, 2)
+#undef FRT_CE
+            if (k[3] < kFar) { *top = r[3]; top += stride; }
+            if (k[2] < kFar) { *top = r[2]; top += stride; }
+            if (k[1] < kFar) { *top = r[1]; top += stride; }
+            if (k[0] < kFar) cur = r[0];
+            else if (top == stk) cur = kDone;
+            else { top -= stride; cur = *top; }
+        }
+    }
+#endif
     for (;;) {
         while (node_phase()) {
             if (VOTE && (cur & 0x80000000u)) continue;      // this lane holds a leaf (or is done): it sits the node step out
