@@ -14,7 +14,8 @@ launches = {}
 for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+    # gpurun MERGES a call's output into the local gpurun_out/: a tag used twice leaves two runs' files in one directory — only the newest counts
+    for f in sorted(glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
