@@ -25,6 +25,7 @@ struct BvhOpt {
     struct N { float lo[3], hi[3]; int parent, c[2]; uint32_t first, count; };
     std::vector<N> n;
     int root = 0;
+    static const int kMaxVisits = 512;
 
     static float area(const float lo[3], const float hi[3]) {
         const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -121,9 +122,12 @@ struct BvhOpt {
             float best = 3.0e38f; int bx = -1;
             while (!pq.empty()) pq.pop();
             pq.push({0.0f, root});
+            // (the search is cut after kMaxVisits candidates: where boxes overlap heavily — coincident geometry — the bound prunes nothing and a full
+            // search would make the pass quadratic; the best position found so far is a valid one)
+            int visits = 0;
             while (!pq.empty()) {
                 const Cand c = pq.top(); pq.pop();
-                if (c.induced + la >= best) break;
+                if (c.induced + la >= best || ++visits > kMaxVisits) break;
                 const float direct = union_area(c.node, l);
                 const float total = c.induced + direct;
                 if (total < best) { best = total; bx = c.node; }

@@ -138,3 +138,30 @@ def test_quad_tree_covers_the_scene_and_fits_the_stack(frt, hostcheck):
     t2, i2, _, _ = hostcheck.trace(deep, o, d.astype(np.float32), 0.0, 3e38, any_hit=False)
     t4, i4, _, _ = hostcheck.trace(deep, o, d.astype(np.float32), 0.0, 3e38, any_hit=False, quantized=2)
     assert np.array_equal(i2, i4) and np.array_equal(t2, t4) and (i2 != 0xFFFFFFFF).mean() > 0.2
+
+
+def test_heavily_overlapping_geometry_builds_in_bounded_time(frt, hostcheck):
+    """20,000 nearly coincident triangles: every box overlaps every other, so the insertion-optimisation pass (frt_bvh_opt.hpp, scenes of 8,192
+    triangles and more) gets no pruning from its bound; its search is cut after a fixed number of candidates, which keeps the pass linear. The tree
+    must still be a valid one: pair-node and quad-node walks agree and the rays that aim at the pile hit it."""
+    import time
+    n = 20000
+    rng = np.random.default_rng(1)
+    pos = np.zeros((3 * n, 4), np.float32); pos[:, 3] = 1.0
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    pos[:, :3] = np.tile(base, (n, 1)) + rng.normal(0, 1e-3, (3 * n, 3)).astype(np.float32)
+    geo = frt.geometry.Geometry(pos, np.zeros((3 * n, 8), np.float32), np.arange(3 * n, dtype=np.uint32))
+    sb = frt.SceneBuilder()
+    mesh = sb.add_mesh(geo)
+    mat = sb.add_material(frt.material_new([0.8, 0.8, 0.8, 1.0]))
+    sb.add_instance(mesh, mat, np.eye(4, dtype=np.float32).T)
+    t0 = time.perf_counter()
+    scene = sb.build()
+    assert time.perf_counter() - t0 < 30.0
+    st = scene.bvh_stats(); q = hostcheck.quad_stats(scene)
+    assert st["depth"] <= 30 and q["stack_walked"] == q["stack_need"] <= 32 and q["triangles"] == n
+    o = np.tile(np.array([[0.25, 0.25, 1.0]], np.float32), (64, 1)) + rng.normal(0, 0.05, (64, 3)).astype(np.float32)
+    d = np.tile(np.array([[0.0, 0.0, -1.0]], np.float32), (64, 1))
+    t2, i2, _, _ = hostcheck.trace(scene, o, d, 0.0, 100.0, any_hit=False)
+    t4, i4, _, _ = hostcheck.trace(scene, o, d, 0.0, 100.0, any_hit=False, quantized=2)
+    assert np.array_equal(i2, i4) and np.array_equal(t2, t4) and (i2 != 0xFFFFFFFF).mean() > 0.5
