@@ -175,6 +175,27 @@ def self_launch(a, argv):
     return 0
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout. Libraries loaded later write there too (gloo announces its peers on std::cout, the HIP runtime
+    complains about a missing amdgpu.ids): from here on file descriptor 1 IS stderr, and emit_result() writes the line to the original stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_result(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def rank_env():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
 
@@ -192,8 +213,8 @@ def dry_run(a):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "config": {"ranks": ranks, "backend": "gloo" if world > 1 else None,
-                                                                        "self_launched": os.environ.get("FRT_BENCH_SELF_LAUNCHED") == "1"}}), flush=True)
+        emit_result({"dry_run": True, "n_gpus": world, "config": {"ranks": ranks, "backend": "gloo" if world > 1 else None,
+                                                                   "self_launched": os.environ.get("FRT_BENCH_SELF_LAUNCHED") == "1"}})
 
 
 # ------------------------------------------------------------------------------------------------------------ measurement
@@ -268,6 +289,7 @@ def main():
     env_world = os.environ.get("WORLD_SIZE")
     if a.gpus > 1 and env_world is None and not a.native:
         return self_launch(a, sys.argv[1:])          # nothing GPU-related has been imported or called yet
+    claim_stdout()                                   # (a rank, or the one process of N = 1 / --native: only the JSON line reaches stdout)
     if a.dry_run:
         return dry_run(a)
     if a.native:
@@ -451,7 +473,7 @@ def main():
             out["config2_4k"] = extra4k
         if cpu:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        emit_result(out)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -487,7 +509,7 @@ def main_native(a):
         mr4, el4, rays4 = run(W4K, H4K, 4, k4)
         out["config2_4k"] = {"workload": "Cornell Box 3840x2160, MAX_DEPTH 8 (BASELINE.json configs[2])", "value": rays4 / el4 / 1e6, "unit": "Mrays/s",
                              "ms_per_step": el4 / k4 * 1e3, "steps": k4, "warmup": 4, "rays_per_frame": rays4 / k4, "rows": mr4.boundaries()}
-    print(json.dumps(out), flush=True)
+    emit_result(out)
 
 
 if __name__ == "__main__":

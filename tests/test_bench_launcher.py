@@ -22,6 +22,7 @@ def test_self_launch_starts_n_ranks(n):
     assert p.returncode == 0, p.stdout + p.stderr
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout                      # ONE JSON line, from rank 0
+    assert p.stdout.strip().splitlines() == lines, p.stdout   # ... and NOTHING else on stdout (gloo announces its peers on std::cout: bench.py turns fd 1 into stderr)
     res = json.loads(lines[0])
     assert res["n_gpus"] == n and [r["rank"] for r in res["config"]["ranks"]] == list(range(n))
     assert len({r["pid"] for r in res["config"]["ranks"]}) == n          # n distinct processes
