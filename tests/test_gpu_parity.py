@@ -490,9 +490,34 @@ def test_bench_self_launch_rehearsal_on_one_gpu(gpu):
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and p.stdout.strip().splitlines() == lines      # the JSON line and nothing else (gloo's chatter goes to stderr)
     res = json.loads(lines[0])
     cfg = res["config"]
     assert res["n_gpus"] == 2 and cfg["process_group_world_size"] == 2 and cfg["allreduce_of_ones"] == 2 and cfg["self_launched"]
     assert [r["rank"] for r in cfg["ranks"]] == [0, 1] and cfg["ranks"][0]["rows"][1] == cfg["ranks"][1]["rows"][0]
     assert res["value"] > 0 and res["scaling"] == "strong"
+
+
+def test_bench_line_contract_at_one_gpu(gpu):
+    """The line the round driver parses: `python bench.py --gpus 1 --steps K --warmup W` prints exactly one line on stdout, a JSON object with the
+    contract's keys, a roofline block (achieved / peak / frac / traffic from the committed counters when they match the kernel sources) and a CPU
+    baseline measured in the same run."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--cpu-frames", "1", "--no-4k"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = p.stdout.strip().splitlines()
+    assert len(out) == 1, p.stdout[:2000]
+    res = json.loads(out[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in res, k
+    assert res["n_gpus"] == 1 and res["steps"] == 8 and res["warmup"] == 2 and res["unit"] == "Mrays/s" and res["dtype"] == "f32" and res["vs_baseline"] is None
+    assert res["value"] > 1000 and 0.5 < res["ms_per_step"] < 20 and res["higher_is_better"] is True and "workload" in res["config"]
+    assert abs(res["value"] - res["config"]["rays_per_frame"] / res["ms_per_step"] / 1e3) < 1e-6 * res["value"]      # Mrays/s = rays per frame / ms per frame
+    roof = res["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "logical_GBs", "stages"):
+        assert k in roof, k
+    cpu = res["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu and cpu["unit"] == "Mrays/s"
