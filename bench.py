@@ -38,25 +38,89 @@ STAGES = ("gbuffer", "temporal", "spatial", "post")
 # 16-byte candidate) + T-merge (read candidate 16, G-buffer 36 + previous 36 + motion 8, previous spatial reservoir 32, write 32) = 212;
 # spatial read 36+32, write 32+8; post read 68, write 20.
 B_PX = {"gbuffer": 44, "temporal": 212, "spatial": 108, "post": 88}
-PMC_JSON = os.path.join(ROOT, "profiles", "r3_pmc.json")     # written by tools/pmc_to_json.py on the GPU box, committed
+def _latest_pmc_json():
+    """profiles/r<N>_pmc.json of the highest round N (written by tools/pmc_to_json.py from the --pmc passes of tools/profile_all.sh, committed)."""
+    import glob, re
+    best = (-1, os.path.join(ROOT, "profiles", "r0_pmc.json"))
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")):
+        m = re.fullmatch(r"r(\d+)_pmc\.json", os.path.basename(f))
+        if m:
+            best = max(best, (int(m.group(1)), f))
+    return best[1]
+
+
+PMC_JSON = _latest_pmc_json()
+
+
+def device_sources():
+    """The files that decide the DEVICE code of lib/libfrt.so: csrc/frt_kernels.hip (the only translation unit with __global__ functions) and
+    what it includes, transitively. csrc/experiments/ is compiled into lib/libfrt_exp.so only (FRT_EXPERIMENTS) and host-only files
+    (frt_bvh_opt.hpp, frt_scene.cpp, frt_loader.cpp, frt_renderer.hip ...) are not device code: editing them does not stale a profile."""
+    import re
+    csrc = os.path.join(ROOT, "fast-raytracing-wgpu_amd", "csrc")
+    seen, todo = [], ["frt_kernels.hip"]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.append(f)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(os.path.join(csrc, f)).read(), re.M):
+            inc = os.path.normpath(os.path.join(os.path.dirname(f), inc))
+            if not inc.startswith("experiments") and os.path.exists(os.path.join(csrc, inc)):
+                todo.append(inc)
+    return sorted(seen)
 
 
 def source_hash():
-    """sha256 over the kernel sources the PMC passes were measured on (csrc/*.hip, *.hpp, the Makefile): a profile of other code is stale."""
-    import glob, hashlib
+    """sha256 over the device sources (device_sources()) and the compiler flags of the Makefile: what the committed counters were measured on."""
+    import hashlib, re
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "fast-raytracing-wgpu_amd", "csrc", "*.h*"))) + [os.path.join(ROOT, "fast-raytracing-wgpu_amd", "Makefile")]:
-        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())       # (the Makefile: compiler flags change the kernels too)
+    csrc = os.path.join(ROOT, "fast-raytracing-wgpu_amd", "csrc")
+    for f in device_sources():
+        h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+    mk = open(os.path.join(ROOT, "fast-raytracing-wgpu_amd", "Makefile")).read()
+    for var in ("ARCH", "FLAGS"):      # (the flags change the kernels too; comments and rules of the Makefile do not)
+        m = re.search(r"^%s\s*\??=\s*((?:.*\\\n)*.*)$" % var, mk, re.M)
+        h.update((var + "=" + " ".join(m.group(1).replace("\\\n", " ").split())).encode() if m else b"?")
     return h.hexdigest()[:16]
 
 
+def code_object_hash(path=None):
+    """sha256 of the gfx950 code objects inside lib/libfrt.so (its .hip_fatbin section): host edits never change it, device edits always do.
+    None when the library (or the section) is absent."""
+    import hashlib, struct
+    path = path or os.path.join(ROOT, "fast-raytracing-wgpu_amd", "lib", "libfrt.so")
+    try:
+        with open(path, "rb") as f:
+            d = f.read()
+    except OSError:
+        return None
+    if d[:4] != b"\x7fELF" or d[4] != 2:
+        return None
+    shoff, = struct.unpack_from("<Q", d, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", d, 0x3A)
+    sec = lambda i: struct.unpack_from("<IIQQQQIIQQ", d, shoff + i * shentsize)
+    str_off = sec(shstrndx)[4]
+    for i in range(shnum):
+        name, _, _, _, off, size = sec(i)[:6]
+        end = d.index(b"\0", str_off + name)
+        if d[str_off + name:end] == b".hip_fatbin":
+            return hashlib.sha256(d[off:off + size]).hexdigest()[:16]
+    return None
+
+
 def load_pmc():
-    """Per-kernel counters of the committed rocprofv3 --pmc passes, or None when they were measured on different kernel sources."""
+    """Per-kernel counters of the committed rocprofv3 --pmc passes. d["stale"] is False when they were measured on these kernels: the device
+    sources + flags hash alike, or the library's code objects do (either is proof; a host-only edit changes neither). A stale profile is
+    still reported — with the flag — so that a record never loses its numbers; tests/test_bench_profile.py fails on the CPU box the moment a
+    commit stales the profile."""
     try:
         d = json.load(open(PMC_JSON))
     except (OSError, ValueError):
         return None
-    return d if d.get("source_hash") == source_hash() else None
+    co = code_object_hash()
+    d["stale"] = not (d.get("source_hash") == source_hash() or (co is not None and d.get("code_object_hash") == co))
+    return d
 
 
 def cpu_share():
@@ -240,7 +304,7 @@ def rays_of(s0, s1):
 
 
 def roofline_block(world, frame_ms, stages, px_rows):
-    """What binds the frame, read from the committed counters (profiles/r3_pmc.json, withheld when measured on other kernel sources).
+    """What binds the frame, read from the committed counters (PMC_JSON; flagged `stale` when measured on other device code).
     The scene is L2-resident, so neither roofline the task names (hbm, mfma) binds: the frame is bound by the LATENCY of dependent vector
     instructions between L1 round trips at 4 waves per SIMD. `bound`/`achieved`/`peak`/`frac` therefore describe the vector ALU
     (wave-instructions x 64 lanes per second against 256 CUs x 4 SIMD-32 x 2.4 GHz); `useful_lane_frac` = that x the lane utilisation is the
@@ -276,9 +340,12 @@ def roofline_block(world, frame_ms, stages, px_rows):
         roof["useful_lane_frac"] = issue * frame_lu if frame_lu else None
         if pmc.get("l1"):
             roof["l1"] = pmc["l1"]          # TCP hit rates / TA busy of the traced kernels (tools/pmc_ta.sh)
-        roof["pmc_source"] = {"file": os.path.relpath(PMC_JSON, ROOT), "source_hash": pmc["source_hash"], "git_head": pmc.get("git_head")}
+        roof["pmc_source"] = {"file": os.path.relpath(PMC_JSON, ROOT), "source_hash": pmc["source_hash"], "code_object_hash": pmc.get("code_object_hash"),
+                              "git_head": pmc.get("git_head"), "stale": pmc["stale"],
+                              "note": "counters of the committed rocprofv3 --pmc passes x this run's frame time; stale = measured on other device code than this library's "
+                                      "(device sources + flags and code objects both hash differently)"}
     elif world == 1:
-        roof["pmc_source"] = f"{os.path.relpath(PMC_JSON, ROOT)} is absent or was measured on other kernel sources: achieved / frac / traffic / hbm_actual / valu_issue withheld"
+        roof["pmc_source"] = f"{os.path.relpath(PMC_JSON, ROOT)} is absent: achieved / frac / traffic / hbm_actual / valu_issue withheld"
     else:
         roof["pmc_source"] = "counters are collected at N = 1 only"
     return roof

@@ -519,5 +519,13 @@ def test_bench_line_contract_at_one_gpu(gpu):
     roof = res["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "logical_GBs", "stages"):
         assert k in roof, k
+    # the counters are numbers in the record (a stale profile blanked them), they come from a profile of THIS device code, and
+    # frac is what the line says it is: VALU wave-instructions x 64 lanes / frame time / peak
+    for k in ("achieved", "frac", "traffic"):
+        assert isinstance(roof[k], float) and roof[k] > 0, (k, roof[k])
+    assert roof["pmc_source"]["stale"] is False, roof["pmc_source"]
+    assert roof["hbm_actual"]["frac"] > 0 and roof["valu_issue"]["frac_at_measured_clock"] > 0
+    want = roof["valu_issue"]["wave_insts_per_frame"] * 64.0 / (res["ms_per_step"] * 1e-3) / 1e12 / roof["peak"]
+    assert abs(roof["frac"] - want) <= 1e-6 * want
     cpu = res["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu and cpu["unit"] == "Mrays/s"

@@ -1,12 +1,12 @@
 """Turn the rocprofv3 --pmc passes of tools/profile_all.sh (gpurun_out/pmc_<tag>_*) and the VALU calibration (gpurun_out/valu_calib.txt)
 into the JSON bench.py reads for its roofline block: per-kernel per-launch means, HBM bytes and VALU wave-instructions per frame, the
-calibrated issue cost, and the hash of the kernel sources they were measured on (bench.py withholds the numbers when the hash differs).
+calibrated issue cost, and the hashes of the device sources / code objects they were measured on (bench.py flags the numbers `stale` when neither matches).
 Run HERE (the repository with .git), after the gpurun call that produced the passes:
     python tools/pmc_to_json.py r3 > profiles/r3_pmc.json"""
 import collections, csv, glob, json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import source_hash     # noqa: E402
+from bench import source_hash, code_object_hash, device_sources     # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "run"
 tab = collections.defaultdict(dict)
@@ -78,7 +78,9 @@ except OSError:
     pass
 sat = calib.get("independent_K8") or calib.get("independent_K4") or {"simd_cycles_per_wave_inst": 2.0, "shader_clock_ghz": 2.4}
 out = {
-    "source_hash": source_hash(),
+    "source_hash": source_hash(),                 # device sources (bench.device_sources) + compiler flags
+    "code_object_hash": code_object_hash(),       # .hip_fatbin of lib/libfrt.so as it stands in this tree (the library the passes ran)
+    "device_sources": device_sources(),
     "git_head": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
     "workload": "bench.py --cpu-frames 0 --no-4k --steps 16 --warmup 4 (1920x1080, two-stream schedule), per-launch means",
     "kernels": kern,
