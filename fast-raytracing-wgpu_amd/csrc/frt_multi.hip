@@ -11,7 +11,11 @@
 // of the loop); here every rank is a device of this process and the orderings are events:
 //   a copy runs on the DESTINATION strip's copy stream, behind (a) the event the SOURCE strip recorded after the kernel that produced the
 //   rows and (b) an event of the destination's own main stream that lies behind the last reader of the halo rows it overwrites;
-//   the consumer stream (main stream, or the edge stream for "mid") then waits for the copy's event.
+//   the consumer stream (main stream, or the edge stream for "mid") then waits for the copy's event;
+//   (c) the SOURCE strip's next writer of the rows waits for the copy's event too (write-after-read): T-merge(f+1) rewrites the temporal
+//   reservoirs the neighbours' "mid" copies of frame f read, the spatial stage of frame f rewrites the spatial reservoirs their "pre" copies of
+//   frame f read, post(f+1) rewrites the accumulation slot their "post" copies read. With balanced strips on healthy devices the copies are long
+//   done by then; a device that lags (shared, throttled) would otherwise have its neighbour's rows overwritten under the copy.
 // Reads gather the strips' rows. Images are bit-identical to a single renderer's (tests: every logical device mapped to ordinal 0).
 // Host side: ONE WORKER THREAD PER STRIP enqueues that strip's launches, copies and event operations (about 85 us of host time per strip and
 // frame: eight strips from one thread would take 0.68 ms per frame against the 0.36 ms a 1/8 strip of a 1080p frame needs on its GPU —
@@ -50,6 +54,8 @@ struct Strip {
     hipStream_t copy = nullptr;                       // this strip's incoming halo rows
     hipEvent_t ev_tm = nullptr, ev_spatial = nullptr, ev_post = nullptr;      // recorded on the main stream behind T-merge / spatial / post of the current frame
     hipEvent_t ev_copy_pre = nullptr, ev_copy_mid = nullptr, ev_copy_post = nullptr;
+    hipEvent_t ev_src = nullptr, ev_gather = nullptr; // gather: behind the strip's producers / behind the copy of its rows into the gathered frame
+    bool gather_pending = false;                      // a gather copy of this strip's rows may still be reading them: the next writers wait for ev_gather
     void* p_res[2] = {nullptr, nullptr};              // device addresses of reservoir_buffers[0 / 1] and accumulation[0 / 1]: fixed for the renderer's life, so a
     void* p_acc[2] = {nullptr, nullptr};              // neighbour's worker thread reads them here instead of through the renderer handle
     std::thread worker;
@@ -65,6 +71,13 @@ struct frt_multi_renderer {
     // worker threads: `job` counts the steps posted so far (two per frame); a worker runs step `job` when it sees the counter move
     std::mutex mu; std::condition_variable cv_post, cv_done;
     uint64_t job = 0; uint32_t done = 0; bool stop = false;
+    int step = 0;                    // the step the posted job runs (0 = A, 1 = B): stated, not derived from the job counter's parity, so that a frame
+                                     // that ended after a failed step A cannot shift every later frame by one step
+    bool failed = false;             // a strip's step failed: half-enqueued frames on the other strips; FRT_ERR_STATE until frt_multi_renderer_clear
+    int inject_strip = -1, inject_step = -1;      // frt_multi_renderer_inject_failure (testing)
+    float jitter[2] = {0.0f, 0.0f};
+    uint32_t peer_pairs = 0, peer_enabled = 0;
+    void* gather_buf = nullptr; size_t gather_bytes = 0;      // read_display / read_buffer: the gathered frame on the first strip's device
     frt_camera_uniform cam{};
 };
 
@@ -170,22 +183,36 @@ int exchange_into(frt_multi_renderer* m, size_t k, Which which, int buf, int ind
 // The two steps of a frame for strip k (see the head of this file). m->frame / m->serial are those of the frame being enqueued.
 int strip_step(frt_multi_renderer* m, size_t k, int step) {
     Strip& s = m->strips[k];
+    const size_t n = m->strips.size();
     const frt_camera_uniform* cam = &m->cam;
     const uint32_t K = m->motion_halo;
-    const bool prev = m->serial > 0 && m->frame > 0;      // a previous frame's rows exist (not after create / reset)
+    // A previous frame's spatial reservoirs exist once ANY frame has been rendered, whatever frame_count says: the reference's host resets
+    // frame_count to 0 on every frame the camera moves (state.rs:152) and T-merge reprojects into the previous reservoirs all the same
+    // (restir.wgsl:846-900 uses frame_count for the seed only). Post ignores its history at frame_count 0 (post.wgsl:187).
+    const bool prev_pre = m->serial > 0, prev_post = m->serial > 0 && m->frame > 0;
+    if ((int)k == m->inject_strip && step == m->inject_step) return set_error(FRT_ERR_HIP, "injected failure (frt_multi_renderer_inject_failure)");
     DevGuard g(s.device);
     hipStream_t q = (hipStream_t)frt_renderer_stream(s.r, 0);
+    hipStream_t qe = (hipStream_t)frt_renderer_stream(s.r, 2);
+    // rule (c): this strip's next writer of rows a neighbour copies waits for that neighbour's copy event
+    auto wait_neighbours = [&](hipStream_t st, hipEvent_t Strip::*ev) -> int {
+        if (k > 0) HIPM_TRY(hipStreamWaitEvent(st, m->strips[k - 1].*ev, 0));
+        if (k + 1 < n) HIPM_TRY(hipStreamWaitEvent(st, m->strips[k + 1].*ev, 0));
+        return FRT_OK;
+    };
     int rc;
     if (step == 0) {
-        if (prev) {
+        if (prev_post) {
             rc = exchange_into(m, k, POST, FRT_BUF_ACCUM, (int)((m->frame - 1u) & 1u), K ? K + kHaloHistory : kHaloHistory);      // a whole frame of slack
             if (rc) return rc;
-            if (K) {
-                rc = exchange_into(m, k, PRE, FRT_BUF_RESERVOIR, 1, K);
-                if (rc) return rc;
-                HIPM_TRY(hipStreamWaitEvent(q, s.ev_copy_pre, 0));
-            }
         }
+        if (prev_pre && K) {
+            rc = exchange_into(m, k, PRE, FRT_BUF_RESERVOIR, 1, K);
+            if (rc) return rc;
+            HIPM_TRY(hipStreamWaitEvent(q, s.ev_copy_pre, 0));
+        }
+        // T-merge(f) rewrites reservoir_buffers[0]: behind the neighbours' "mid" copies of frame f-1 (recorded in that frame's step B)
+        if (m->serial > 0 && (rc = wait_neighbours(q, &Strip::ev_copy_mid))) return rc;
         rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_GBUFFER | FRT_PHASE_TEMPORAL);      // T-merge (G-buffer + T-trace normally ran ahead of the frame)
         if (rc) return rc;
         HIPM_TRY(hipEventRecord(s.ev_tm, q));
@@ -193,13 +220,29 @@ int strip_step(frt_multi_renderer* m, size_t k, int step) {
     }
     rc = exchange_into(m, k, MID, FRT_BUF_RESERVOIR, 0, kHaloReservoir);      // behind this strip's and its neighbours' T-merge
     if (rc) return rc;
+    // the spatial stage rewrites reservoir_buffers[1] (interior launch: main stream; edge launches: the edge stream, whose second edge stream is
+    // ordered behind it): behind the neighbours' "pre" copies of THIS frame (enqueued in step A; the host barrier between the steps recorded them)
+    if (prev_pre && K) {
+        if ((rc = wait_neighbours(q, &Strip::ev_copy_pre))) return rc;
+        if (qe != q && (rc = wait_neighbours(qe, &Strip::ev_copy_pre))) return rc;
+    }
+    if (s.gather_pending) {      // ... and raw / reservoirs / display rows a gather may still be copying
+        HIPM_TRY(hipStreamWaitEvent(q, s.ev_gather, 0));
+        if (qe != q) HIPM_TRY(hipStreamWaitEvent(qe, s.ev_gather, 0));
+        s.gather_pending = false;
+    }
     rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_SPATIAL_INNER);       // interior rows: need nothing from a neighbour
     if (rc) return rc;
-    HIPM_TRY(hipStreamWaitEvent((hipStream_t)frt_renderer_stream(s.r, 2), s.ev_copy_mid, 0));      // the edge rows' stream waits for the neighbours' reservoirs
+    HIPM_TRY(hipStreamWaitEvent(qe, s.ev_copy_mid, 0));      // the edge rows' stream waits for the neighbours' reservoirs
     rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_SPATIAL_EDGE);
     if (rc) return rc;
     HIPM_TRY(hipEventRecord(s.ev_spatial, q));
-    if (prev) HIPM_TRY(hipStreamWaitEvent(q, s.ev_copy_post, 0));
+    if (prev_post) {
+        HIPM_TRY(hipStreamWaitEvent(q, s.ev_copy_post, 0));
+        // post(f) rewrites the accumulation slot the neighbours' "post" copies of frame f-1 read; their copies of THIS frame (step A, same copy
+        // streams, behind those) are what the events now stand for: waiting for them covers both
+        if ((rc = wait_neighbours(q, &Strip::ev_copy_post))) return rc;
+    }
     rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_POST);
     if (rc) return rc;
     HIPM_TRY(hipEventRecord(s.ev_post, q));
@@ -209,13 +252,15 @@ int strip_step(frt_multi_renderer* m, size_t k, int step) {
 void worker_main(frt_multi_renderer* m, size_t k) {
     uint64_t seen = 0;
     for (;;) {
+        int step;
         {
             std::unique_lock<std::mutex> lk(m->mu);
             m->cv_post.wait(lk, [&] { return m->stop || m->job != seen; });
             if (m->stop) return;
             seen = m->job;
+            step = m->step;
         }
-        const int rc = strip_step(m, k, (int)((seen - 1u) & 1u));
+        const int rc = strip_step(m, k, step);
         Strip& s = m->strips[k];
         s.status = rc;
         if (rc) s.message = frt_last_error();      // (thread-local in the library: copy it out of this thread)
@@ -227,10 +272,10 @@ void worker_main(frt_multi_renderer* m, size_t k) {
 }
 
 // Run one step on every strip's worker and wait until all have enqueued it.
-int run_step(frt_multi_renderer* m) {
+int run_step(frt_multi_renderer* m, int step) {
     {
         std::lock_guard<std::mutex> lk(m->mu);
-        m->done = 0; m->job += 1;
+        m->done = 0; m->step = step; m->job += 1;
     }
     m->cv_post.notify_all();
     {
@@ -275,7 +320,7 @@ frt_multi_renderer* frt_multi_renderer_create(const frt_scene* scene, uint32_t w
         if (!s.r) { frt_multi_renderer_destroy(m); return nullptr; }
         DevGuard g(s.device);
         bool ok = hipStreamCreateWithFlags(&s.copy, hipStreamNonBlocking) == hipSuccess;
-        for (hipEvent_t* e : {&s.ev_tm, &s.ev_spatial, &s.ev_post, &s.ev_copy_pre, &s.ev_copy_mid, &s.ev_copy_post})
+        for (hipEvent_t* e : {&s.ev_tm, &s.ev_spatial, &s.ev_post, &s.ev_copy_pre, &s.ev_copy_mid, &s.ev_copy_post, &s.ev_src, &s.ev_gather})
             ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
         if (!ok) { set_error(FRT_ERR_HIP, "multi_renderer_create: stream / event creation failed"); frt_multi_renderer_destroy(m); return nullptr; }
         uint32_t bpp = 0;
@@ -290,9 +335,16 @@ frt_multi_renderer* frt_multi_renderer_create(const frt_scene* scene, uint32_t w
     for (uint32_t k = 0; k + 1 < ndev; ++k) {
         const int a = dev[k], b = dev[k + 1];
         if (a == b) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) { DevGuard g(a); (void)hipDeviceEnablePeerAccess(b, 0); }
-        if (hipDeviceCanAccessPeer(&can, b, a) == hipSuccess && can) { DevGuard g(b); (void)hipDeviceEnablePeerAccess(a, 0); }
+        m->peer_pairs += 1;
+        int can = 0, both = 0;
+        auto enable = [&](int from, int to) {
+            if (hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can) return;
+            DevGuard g(from);
+            const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) both += 1;
+        };
+        enable(a, b); enable(b, a);
+        if (both == 2) m->peer_enabled += 1;
         (void)hipGetLastError();      // "already enabled" is not an error here
     }
     return m;
@@ -310,21 +362,37 @@ void frt_multi_renderer_destroy(frt_multi_renderer* m) {
         DevGuard g(s.device);
         if (s.r) (void)frt_renderer_sync(s.r);
         if (s.copy) { (void)hipStreamSynchronize(s.copy); (void)hipStreamDestroy(s.copy); }
-        for (hipEvent_t e : {s.ev_tm, s.ev_spatial, s.ev_post, s.ev_copy_pre, s.ev_copy_mid, s.ev_copy_post}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {s.ev_tm, s.ev_spatial, s.ev_post, s.ev_copy_pre, s.ev_copy_mid, s.ev_copy_post, s.ev_src, s.ev_gather}) if (e) (void)hipEventDestroy(e);
         if (s.r) frt_renderer_destroy(s.r);
     }
+    if (m->gather_buf && !m->strips.empty()) { DevGuard g(m->strips[0].device); (void)hipFree(m->gather_buf); }
     delete m;
 }
 
 // Renderer::render, src/renderer.rs:349 — ONE call, one frame, on every device. Asynchronous on the GPUs (returns when the frame is enqueued).
 int frt_multi_renderer_render(frt_multi_renderer* m, const frt_camera_uniform* cam) {
     if (!m || !cam) return set_error(FRT_ERR_INVALID_ARG, "multi render: null");
-    if (m->strips.size() == 1) { const int rc = frt_renderer_render(m->strips[0].r, cam); if (rc == FRT_OK) { m->frame += 1; m->serial += 1; } return rc; }
+    if (m->failed) return set_error(FRT_ERR_STATE, "multi render: an earlier frame failed on one strip in the middle of its steps; call frt_multi_renderer_clear");
+    if (m->strips.size() == 1) {
+        Strip& s0 = m->strips[0];
+        if (s0.gather_pending) {      // a gather on the caller's stream may still be copying the rows this frame rewrites
+            DevGuard g(s0.device);
+            HIPM_TRY(hipStreamWaitEvent((hipStream_t)frt_renderer_stream(s0.r, 0), s0.ev_gather, 0));
+            s0.gather_pending = false;
+        }
+        int rc = m->inject_strip == 0 ? set_error(FRT_ERR_HIP, "injected failure (frt_multi_renderer_inject_failure)") : frt_renderer_render(s0.r, cam);
+        m->inject_strip = m->inject_step = -1;
+        if (rc == FRT_OK) { m->frame += 1; m->serial += 1; }
+        else if (rc == FRT_ERR_HIP) m->failed = true;
+        return rc;
+    }
     m->cam = *cam;
-    int rc = run_step(m);      // step A on every strip; the return is the host barrier: every ev_tm is recorded
-    if (rc) return rc;
-    rc = run_step(m);          // step B
-    if (rc) return rc;
+    // Step A on every strip; the return is the host barrier: every ev_tm is recorded. A strip that fails leaves the others with an open, half-enqueued
+    // frame (their T-merge is in flight, step B will never run): the handle is FAILED until frt_multi_renderer_clear.
+    int rc = run_step(m, 0);
+    if (rc == FRT_OK) rc = run_step(m, 1);
+    m->inject_strip = m->inject_step = -1;
+    if (rc) { m->failed = true; return rc; }
     m->frame += 1; m->serial += 1;
     return FRT_OK;
 }
@@ -344,8 +412,48 @@ uint32_t frt_multi_renderer_frame_count(const frt_multi_renderer* m) { return m 
 
 int frt_multi_renderer_reset(frt_multi_renderer* m) {      // frame_count = 0 (state.rs:152): buffers keep their contents
     if (!m) return set_error(FRT_ERR_INVALID_ARG, "multi reset: null");
+    if (m->failed) return set_error(FRT_ERR_STATE, "multi reset: the handle is failed; call frt_multi_renderer_clear");
     for (Strip& s : m->strips) { int rc = frt_renderer_reset(s.r); if (rc) return rc; }
     m->frame = 0;
+    return FRT_OK;
+}
+
+// Back to the state right after create, on every strip; the way out of the failed state. Waits for the devices first: no copy or kernel of a
+// half-enqueued frame is in flight afterwards, and every event that a later frame waits for has either completed or is recorded anew before.
+int frt_multi_renderer_clear(frt_multi_renderer* m) {
+    if (!m) return set_error(FRT_ERR_INVALID_ARG, "multi clear: null");
+    int first = FRT_OK;
+    for (Strip& s : m->strips) {
+        DevGuard g(s.device);
+        (void)hipStreamSynchronize(s.copy);
+        const int rc = frt_renderer_clear(s.r);      // syncs the strip's streams, zeroes its targets and counters, closes an open frame, clears `failed`
+        if (rc && !first) first = rc;
+        (void)hipStreamSynchronize(s.copy);
+        s.gather_pending = false;
+        s.status = FRT_OK; s.message.clear();
+    }
+    if (first) return first;      // (a device that does not come back: the handle stays failed)
+    m->frame = 0; m->serial = 0; m->failed = false; m->inject_strip = m->inject_step = -1;
+    return FRT_OK;
+}
+
+int frt_multi_renderer_set_jitter(frt_multi_renderer* m, float jx, float jy) {
+    if (!m) return set_error(FRT_ERR_INVALID_ARG, "multi set_jitter: null");
+    if (m->strips.size() > 1 && (jx != 0.0f || jy != 0.0f))
+        return set_error(FRT_ERR_INVALID_ARG, "multi set_jitter: a non-zero post jitter (bilinear taps with Repeat addressing read the opposite image edge) is not supported when the frame is cut into strips");
+    m->jitter[0] = jx; m->jitter[1] = jy;
+    return frt_renderer_set_jitter(m->strips[0].r, jx, jy);
+}
+
+int frt_multi_renderer_inject_failure(frt_multi_renderer* m, uint32_t strip, int step) {
+    if (!m || strip >= m->strips.size() || (step != 0 && step != 1)) return set_error(FRT_ERR_INVALID_ARG, "multi inject_failure: bad arguments");
+    m->inject_strip = (int)strip; m->inject_step = step;
+    return FRT_OK;
+}
+
+int frt_multi_renderer_peer_access(const frt_multi_renderer* m, uint32_t out[2]) {
+    if (!m || !out) return set_error(FRT_ERR_INVALID_ARG, "multi peer_access: null");
+    out[0] = m->peer_pairs; out[1] = m->peer_enabled;
     return FRT_OK;
 }
 
@@ -355,16 +463,57 @@ int frt_multi_renderer_boundaries(const frt_multi_renderer* m, uint32_t* out) {
     return (int)m->strips.size();
 }
 
-// Gather: every strip's own rows of a target into one full-frame host buffer.
+// Device-side gather: every strip's own rows of a target into ONE full-frame buffer in the memory of `device`. Each strip's rows travel on that
+// strip's copy stream (peer copy over xGMI; a plain device-to-device copy on the same device), behind an event recorded on the strip's main stream
+// after frt_renderer_fence (= behind everything the strip has enqueued, the ahead stream included). ev_gather of a strip stands for "my rows have
+// been copied": the caller's stream waits for all of them, and so do the strip's next writers of those rows (strip_step, gather_pending).
+int frt_multi_renderer_gather(frt_multi_renderer* m, int buf, int index, int32_t device, void* dst, void* stream) {
+    const uint32_t bpp = bpp_of_buf(buf);
+    if (!m || !dst || !bpp) return set_error(FRT_ERR_INVALID_ARG, "multi gather: bad arguments");
+    if (device < 0 || device >= frt_device_count()) return set_error(FRT_ERR_INVALID_ARG, "multi gather: device ordinal out of range");
+    if (m->failed) return set_error(FRT_ERR_STATE, "multi gather: the handle is failed; call frt_multi_renderer_clear");
+    const size_t pitch = (size_t)m->W * bpp;
+    for (Strip& s : m->strips) {
+        void* src = nullptr;
+        int rc = frt_renderer_buffer_info(s.r, buf, index, &src, nullptr);
+        if (rc) return rc;
+        rc = frt_renderer_fence(s.r);
+        if (rc) return rc;
+        DevGuard g(s.device);
+        hipStream_t q = (hipStream_t)frt_renderer_stream(s.r, 0);
+        HIPM_TRY(hipEventRecord(s.ev_src, q));
+        HIPM_TRY(hipStreamWaitEvent(s.copy, s.ev_src, 0));
+        const size_t off = pitch * s.rb, bytes = pitch * (s.re - s.rb);
+        if (s.device == device) HIPM_TRY(hipMemcpyAsync((uint8_t*)dst + off, (const uint8_t*)src + off, bytes, hipMemcpyDeviceToDevice, s.copy));
+        else HIPM_TRY(hipMemcpyPeerAsync((uint8_t*)dst + off, device, (const uint8_t*)src + off, s.device, bytes, s.copy));
+        HIPM_TRY(hipEventRecord(s.ev_gather, s.copy));
+        s.gather_pending = true;
+    }
+    DevGuard g(device);
+    for (Strip& s : m->strips) {
+        if (stream) HIPM_TRY(hipStreamWaitEvent((hipStream_t)stream, s.ev_gather, 0));
+        else HIPM_TRY(hipEventSynchronize(s.ev_gather));
+    }
+    return FRT_OK;
+}
+
+// Full-frame read-back: the device-side gather above into a buffer on the first strip's device, then ONE device-to-host copy (the reference reads
+// one texture per presented frame, state.rs:226-278; strip by strip through the host this was N synchronisations + N copies).
 int frt_multi_renderer_read_buffer(frt_multi_renderer* m, int buf, int index, void* out) {
     const uint32_t bpp = bpp_of_buf(buf);
     if (!m || !out || !bpp) return set_error(FRT_ERR_INVALID_ARG, "multi read_buffer: bad arguments");
-    int rc = frt_multi_renderer_sync(m);
-    if (rc) return rc;
-    for (Strip& s : m->strips) {
-        rc = frt_renderer_read_rows(s.r, buf, index, s.rb, s.re, (uint8_t*)out + (size_t)m->W * bpp * s.rb);
-        if (rc) return rc;
+    const size_t bytes = (size_t)m->W * m->H * bpp;
+    const int dev = m->strips[0].device;
+    DevGuard g(dev);
+    if (m->gather_bytes < bytes) {
+        if (m->gather_buf) (void)hipFree(m->gather_buf);
+        m->gather_buf = nullptr; m->gather_bytes = 0;
+        HIPM_TRY(hipMalloc(&m->gather_buf, bytes));
+        m->gather_bytes = bytes;
     }
+    int rc = frt_multi_renderer_gather(m, buf, index, dev, m->gather_buf, nullptr);
+    if (rc) return rc;
+    HIPM_TRY(hipMemcpy(out, m->gather_buf, bytes, hipMemcpyDeviceToHost));
     return FRT_OK;
 }
 int frt_multi_renderer_read_display(frt_multi_renderer* m, uint8_t* rgba8) { return frt_multi_renderer_read_buffer(m, FRT_BUF_DISPLAY, 0, rgba8); }

@@ -128,6 +128,11 @@ SYMBOLS = {
     "frt_multi_renderer_sync": (C.c_int, [_P]),
     "frt_multi_renderer_frame_count": (_U32, [_P]),
     "frt_multi_renderer_reset": (C.c_int, [_P]),
+    "frt_multi_renderer_clear": (C.c_int, [_P]),
+    "frt_multi_renderer_set_jitter": (C.c_int, [_P, C.c_float, C.c_float]),
+    "frt_multi_renderer_gather": (C.c_int, [_P, C.c_int, C.c_int, C.c_int32, _P, _P]),
+    "frt_multi_renderer_peer_access": (C.c_int, [_P, _P]),
+    "frt_multi_renderer_inject_failure": (C.c_int, [_P, _U32, C.c_int]),
     "frt_multi_renderer_read_display": (C.c_int, [_P, _P]),
     "frt_multi_renderer_read_accum": (C.c_int, [_P, _P]),
     "frt_multi_renderer_read_buffer": (C.c_int, [_P, C.c_int, C.c_int, _P]),

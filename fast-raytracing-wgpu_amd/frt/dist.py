@@ -59,12 +59,18 @@ class StripPlan:
             out.append((self.rank + 1, buf, index, (re - rows, re), (re, re + rows)))
         return out
 
-    def transfers(self, frame, when="mid"):
-        """[(peer, buf, index, send_rows, recv_rows)] for frame `frame`.
-        when="pre": before its T-merge (moving camera only); "mid": between T-merge and the spatial stage; "post": before its post stage."""
+    def transfers(self, frame, when="mid", serial=None):
+        """[(peer, buf, index, send_rows, recv_rows)] for the frame whose frame_count is `frame`.
+        when="pre": before its T-merge (moving camera only); "mid": between T-merge and the spatial stage; "post": before its post stage.
+        serial: frames rendered since the renderers were created, for hosts that RESET frame_count while the camera moves (state.rs:152): the
+        previous frame's spatial reservoirs exist — and T-merge reprojects into them — whatever frame_count says, so "pre" is gated on
+        `serial`, not on `frame` (default: serial = frame, a counter that never restarts). Post ignores its history at frame_count 0
+        (post.wgsl:187): "post" is gated on `frame`."""
         hist = (frame - 1) % 2          # post.rs:209-224: history = the slot written by the previous frame
+        if serial is None:
+            serial = frame
         if when == "pre":
-            if self.motion_halo == 0 or frame == 0:
+            if self.motion_halo == 0 or serial == 0:
                 return []
             return self._pairs(BUF_RESERVOIR, 1, self.motion_halo)             # previous spatial reservoirs (reservoir_buffers[1])
         if when == "post":
@@ -132,12 +138,12 @@ class _Exchange:
         self.works, self.recvs = [], []
 
 
-def start_exchange(access, plan, frame, group=None, when="mid"):
+def start_exchange(access, plan, frame, group=None, when="mid", serial=None):
     """Post one batched exchange with both vertical neighbours (torch.distributed; nccl = RCCL, or gloo). Returns an _Exchange or None.
     With the nccl backend the transfer is ordered behind the torch stream that is current HERE and finish() orders the stream that is
     current THERE behind it: callers pick the streams (render_strip_frame)."""
     import torch.distributed as dist
-    tr = plan.transfers(frame, when)
+    tr = plan.transfers(frame, when, serial) if serial is not None else plan.transfers(frame, when)
     if not tr:
         return None
     ops, recvs = [], []
@@ -156,7 +162,7 @@ def exchange_halos(access, plan, frame, group=None, when="mid"):
         ex.finish()
 
 
-def render_strip_frame(r, access, plan, cam, frame, frt, group=None):
+def render_strip_frame(r, access, plan, cam, frame, frt, group=None, serial=None):
     """One frame of one rank's strip renderer `r` (frt.Renderer on torch's current stream, buffers in `access`'s arena).
 
     Everything a transfer touches (reservoirs, accumulation) is produced on the renderer's main stream = torch's current stream, so the
@@ -164,7 +170,7 @@ def render_strip_frame(r, access, plan, cam, frame, frt, group=None):
     arrive. The "mid" rows are posted behind T-merge and overlap the interior rows of the spatial stage; only its edge rows wait.
     With a host-staged transport (gloo rehearsal, `access.staging`) start_exchange blocks in the device-to-host copy; same order."""
     post = start_exchange(access, plan, frame, group, when="post")      # behind post(f-1)
-    pre = start_exchange(access, plan, frame, group, when="pre")        # behind spatial(f-1) (moving camera only)
+    pre = start_exchange(access, plan, frame, group, when="pre", serial=serial)        # behind spatial(f-1) (moving camera only)
     if pre:
         pre.finish()
     r.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)        # T-merge(f) (G-buffer + T-trace ran ahead of the frame)
@@ -188,12 +194,12 @@ def check_halo(renderer):
         raise RuntimeError(f"{n} previous-frame reads fell outside the strip's motion halo: raise motion_halo (camera moves too fast for it)")
 
 
-def exchange_halos_host(renderers, plans, frame, when="mid"):
+def exchange_halos_host(renderers, plans, frame, when="mid", serial=None):
     """Same exchange between strip renderers living in ONE process (tests on a single GPU): rows go through host memory
     (read_rows / write_rows wait for everything the renderers have enqueued)."""
     by_rank = {p.rank: r for r, p in zip(renderers, plans)}
     for r, p in zip(renderers, plans):
-        for peer, buf, index, srows, _ in p.transfers(frame, when):
+        for peer, buf, index, srows, _ in (p.transfers(frame, when, serial) if serial is not None else p.transfers(frame, when)):
             data = r.read_rows(buf, index, *srows)
             by_rank[peer].write_rows(buf, index, *srows, data)     # the sender's rows land at the same image rows of the peer
 

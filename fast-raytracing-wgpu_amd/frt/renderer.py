@@ -166,6 +166,26 @@ class MultiRenderer:
     def reset(self):
         check(lib().frt_multi_renderer_reset(self._h))
 
+    def clear(self):
+        """Back to the state right after creation on every strip; the way out of the failed state (a strip's step failed mid-frame)."""
+        check(lib().frt_multi_renderer_clear(self._h))
+
+    def set_jitter(self, jx, jy):
+        check(lib().frt_multi_renderer_set_jitter(self._h, float(jx), float(jy)))
+
+    def inject_failure(self, strip, step):
+        """Testing: the next render call fails on `strip` in step 0 (T-merge half) or 1 (spatial + post half)."""
+        check(lib().frt_multi_renderer_inject_failure(self._h, strip, step))
+
+    def peer_access(self):
+        out = (C.c_uint32 * 2)()
+        check(lib().frt_multi_renderer_peer_access(self._h, out))
+        return {"neighbour_pairs_on_different_devices": int(out[0]), "pairs_with_peer_access": int(out[1])}
+
+    def gather(self, buf, index, device, dst_ptr, stream=None):
+        """Device-side gather of every strip's rows of `buf`[index] into the full-frame device buffer at `dst_ptr` on HIP device `device`."""
+        check(lib().frt_multi_renderer_gather(self._h, buf, index, device, C.c_void_p(dst_ptr), C.c_void_p(stream) if stream else None))
+
     def boundaries(self):
         out = (C.c_uint32 * (self.ndev + 1))()
         check(lib().frt_multi_renderer_boundaries(self._h, out))

@@ -286,7 +286,25 @@ int frt_multi_renderer_render(frt_multi_renderer* m, const frt_camera_uniform* c
 int frt_multi_renderer_sync(frt_multi_renderer* m);
 uint32_t frt_multi_renderer_frame_count(const frt_multi_renderer* m);                             /* renderer.frame_count, :198 */
 int frt_multi_renderer_reset(frt_multi_renderer* m);                                              /* frame_count = 0, state.rs:152 */
-int frt_multi_renderer_read_display(frt_multi_renderer* m, uint8_t* rgba8);                       /* post_processed_texture, state.rs:226-278 (gathers the strips) */
+/* A strip whose step fails (a HIP error in the middle of a frame) leaves the other strips with a half-enqueued frame: the handle is then FAILED and
+ * every render call returns FRT_ERR_STATE until frt_multi_renderer_clear, which waits for the devices, closes every strip's open frame and puts every
+ * strip back into the state right after create (frt_renderer_clear: zeroed targets, frame_count = 0, stats = 0). */
+int frt_multi_renderer_clear(frt_multi_renderer* m);
+/* PostParams.jitter (renderer.rs:14, :361-379). Only (0, 0) — the shipped reference, camera.rs:202-203 — is accepted when the frame is cut into
+ * strips: post's bilinear taps use Repeat addressing and read the opposite image edge (post.wgsl:72-78), which lives on another device. */
+int frt_multi_renderer_set_jitter(frt_multi_renderer* m, float jitter_x, float jitter_y);
+/* Device-side gather (state.rs:226-278 reads ONE texture per frame): every strip's own rows of `buf`[index] are copied into the full-frame buffer
+ * `dst` in the memory of HIP device `device` — peer copies over xGMI on the strips' copy streams, ordered behind the frames enqueued so far, no host
+ * staging. `stream` (a hipStream_t of `device`) is ordered behind the copies; stream = NULL: the call returns when the rows have arrived.
+ * The next frame's writers of those rows are ordered behind the copies by the library. dst: width * height * bytes-per-pixel of `buf`. */
+int frt_multi_renderer_gather(frt_multi_renderer* m, int buf, int index, int32_t device, void* dst, void* stream);
+/* out[0] = neighbouring strip pairs on different devices, out[1] = of those, pairs with direct peer access enabled in both directions */
+int frt_multi_renderer_peer_access(const frt_multi_renderer* m, uint32_t out[2]);
+/* TESTING: the next render call fails on strip `strip` in step `step` (0: T-merge half of the frame, 1: spatial + post half) with FRT_ERR_HIP,
+ * as if a HIP call had failed there — how tests reach the failed state above without breaking a device. */
+int frt_multi_renderer_inject_failure(frt_multi_renderer* m, uint32_t strip, int step);
+/* post_processed_texture, state.rs:226-278: frt_multi_renderer_gather on the first strip's device + ONE device-to-host copy */
+int frt_multi_renderer_read_display(frt_multi_renderer* m, uint8_t* rgba8);
 int frt_multi_renderer_read_accum(frt_multi_renderer* m, float* rgba32f);
 int frt_multi_renderer_read_buffer(frt_multi_renderer* m, int buf, int index, void* out);         /* any target, every strip's own rows */
 int frt_multi_renderer_stats(frt_multi_renderer* m, frt_stats* out);                              /* summed over the strips */

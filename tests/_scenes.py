@@ -47,12 +47,15 @@ class DualBuilder:
         self.fb.add_light(light)
         self.orc.L.orc_scene_add_light(self.oh, C.byref(light))
 
-    def build(self):
+    def build(self, share_bvh=True):
+        """share_bvh: the oracle walks the PRODUCT's canonical BVH2 (north_star: "CPU tracer over the same BVH"). False: the oracle is handed nothing
+        the product built — its renderer must then be created with use_bvh = False (brute force over all triangles)."""
         from _oracle import OrcScene
         self.fb.build()
         self.orc.L.orc_scene_build(self.oh)
         osc = OrcScene(self.orc, self.oh)
-        osc.set_bvh(self.fb.get("bvh2_nodes"), self.fb.get("bvh2_tri_index"))
+        if share_bvh:
+            osc.set_bvh(self.fb.get("bvh2_nodes"), self.fb.get("bvh2_tri_index"))
         return self.fb, osc
 
 
@@ -77,7 +80,7 @@ def _emissive(frt, light_index, rgb, intensity):
     return m
 
 
-def bumpy_sphere_in_box(frt, orc, subdiv=6):
+def bumpy_sphere_in_box(frt, orc, subdiv=6, share_bvh=True):
     """config 3 stand-in. subdiv 6 -> 81,920 triangles (+ 12 wall/light triangles)."""
     b = DualBuilder(frt, orc)
     plane = b.add_mesh(*_geo(frt, "create_plane"))
@@ -96,7 +99,7 @@ def bumpy_sphere_in_box(frt, orc, subdiv=6):
     b.add_instance(plane, lm, ref[5, 5:21].view(np.float32))
     b.add_light(_quad_light(frt, (0, 0.99, 0), 0.25, (1, 1, 1, 10)))
     b.add_instance(blob, white, _mat(0, -0.4, 0, 0.6, 0.6, 0.6))
-    return b.build()
+    return b.build(share_bvh)
 
 
 def colonnade(frt, orc, nx=12, nz=4, subdiv=4):

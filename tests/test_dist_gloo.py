@@ -83,3 +83,17 @@ def test_strip_plan_geometry(frt):
     assert sends == recvs
     with pytest.raises(ValueError):
         StripPlan(100, 3, 0, [0, 50, 55, 100])
+
+
+def test_pre_rows_are_gated_on_frames_rendered_not_on_frame_count(frt):
+    """A host that resets frame_count while the camera moves (state.rs:152) passes frame = 0 every frame: the previous spatial reservoirs exist all
+    the same and T-merge reprojects into them, so the "pre" transfer follows `serial` (frames rendered since creation); post ignores its history at
+    frame_count 0 (post.wgsl:187), so "post" follows `frame`."""
+    from frt.dist import StripPlan, BUF_RESERVOIR
+    p = StripPlan(96, 3, 1, motion_halo=6)
+    assert p.transfers(0, "pre") == [] and p.transfers(0, "pre", serial=0) == []
+    pre = p.transfers(0, "pre", serial=3)
+    assert len(pre) == 2 and all(t[1] == BUF_RESERVOIR and t[2] == 1 and t[3][1] - t[3][0] == 6 for t in pre)
+    assert p.transfers(0, "post", serial=3) == [] and len(p.transfers(2, "post", serial=3)) == 2
+    assert len(p.transfers(5, "pre")) == 2            # a counter that never restarts: serial defaults to frame
+    assert StripPlan(96, 3, 1).transfers(4, "pre", serial=4) == []      # static camera: no motion halo, no "pre" rows

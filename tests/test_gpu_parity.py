@@ -11,11 +11,11 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4    # per-pixel L_inf on the accumulation buffer (north_star)
 
 
-def _strip_frame(frt, strips, plans, cam, f):
+def _strip_frame(frt, strips, plans, cam, f, serial=None):
     """One frame of several strip renderers living in this process, rows exchanged through the host: the three exchanges of
     frt/dist.py in their places, the spatial stage issued as interior rows, then edge rows (the overlap form bench.py uses)."""
     from frt.dist import exchange_halos_host
-    exchange_halos_host(strips, plans, f, when="pre")
+    exchange_halos_host(strips, plans, f, when="pre", serial=serial)
     for s in strips: s.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
     for s in strips: s.render_phases(cam, frt.PHASE_SPATIAL_INNER)
     exchange_halos_host(strips, plans, f, when="mid")
@@ -49,6 +49,28 @@ def test_kernels_match_oracle_every_buffer(gpu, orc, which, W, H, depth, frames)
     assert np.abs(got - want).max() <= TOL
     st, so = r.stats(), ro.stats()["total"]
     assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])      # device ray counters are exact
+
+
+@pytest.mark.parametrize("which,W,H,depth,frames", [("cornell", 128, 128, 8, 3), ("blob5k", 64, 48, 8, 2)])
+def test_kernels_match_the_brute_force_oracle(gpu, orc, which, W, H, depth, frames):
+    """The one comparison in which NO product data feeds the checker (parity caveat): the oracle is never handed the product's BVH —
+    every one of its rays is a scalar loop over all triangles of its own scene (BASELINE.json configs[0]'s "scalar loop over the triangles") —
+    and the HIP path, which walks its own tree, must still agree on every buffer of every frame and on the exact ray counts. Hits are defined
+    by the triangle test alone (frt_trace.hpp: hit semantics), so any tree may only prune."""
+    frt = gpu
+    import _scenes
+    if which == "cornell":
+        fs, os_ = frt.scenes.create_cornell_box(), orc.cornell()
+    else:
+        fs, os_ = _scenes.bumpy_sphere_in_box(frt, orc, subdiv=4, share_bvh=False)
+    r = frt.Renderer(fs, W, H, max_depth=depth, flags=frt.FLAG_PIPELINE)
+    ro = os_.renderer(W, H, depth, False, 16)          # use_bvh = False: brute force
+    for f in range(frames):
+        cam = frt.CameraController().build_uniform(W / H, f, fs.num_lights)
+        r.render(cam); ro.render(cam)
+        compare_all(r.read_buffer, ro.read, f, f"{which} {W}x{H} depth {depth}, brute-force oracle")
+    st, so = r.stats(), ro.stats()["total"]
+    assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
 
 
 @pytest.mark.parametrize("depth", [1, 8])
@@ -287,6 +309,33 @@ def test_moving_camera_strips_equal_whole_image(gpu):
             with pytest.raises(RuntimeError):
                 for s in strips: check_halo(s)
     assert whole.stats()["halo_overflow"] == 0
+
+
+def test_moving_camera_strips_with_the_counter_reset_every_frame(gpu):
+    """The reference's host loop while the camera moves (state.rs:152: frame_count = 0 every such frame) over strips: the "pre" rows — the previous
+    frame's spatial reservoirs, which T-merge reprojects into whatever frame_count says — are gated on the frames rendered since creation
+    (StripPlan.transfers(..., serial)), not on frame_count."""
+    frt = gpu
+    import _scenes
+    from frt.dist import StripPlan, check_halo
+    W, H, N, K = 192, 144, 6, 6
+    fs = frt.scenes.create_cornell_box()
+    cams = _scenes.moving_camera_uniforms(frt, W / H, 2, N)
+    whole = frt.Renderer(fs, W, H)
+    plans = [StripPlan(H, 3, k, motion_halo=K) for k in range(3)]
+    strips = [frt.Renderer(fs, W, H, rows=(p.row_begin, p.row_end), motion_halo=K, flags=frt.FLAG_PIPELINE) for p in plans]
+    for f, cam in enumerate(cams):
+        if f > 0:
+            whole.reset()
+            for s in strips: s.reset()
+        cam.frame_count = 0
+        whole.render(cam)
+        _strip_frame(frt, strips, plans, cam, 0, serial=f)
+        want, wd = whole.read_accum(), whole.read_display()
+        for s, p in zip(strips, plans):
+            assert np.array_equal(s.read_accum()[p.row_begin:p.row_end], want[p.row_begin:p.row_end]), (f, p.rank)
+            assert np.array_equal(s.read_display()[p.row_begin:p.row_end], wd[p.row_begin:p.row_end]), (f, p.rank)
+    for s in strips: check_halo(s)
 
 
 @pytest.mark.parametrize("flags", [0, 8], ids=["plain", "side-stream"])

@@ -99,6 +99,107 @@ def test_multi_reset_and_errors(gpu):
         frt.MultiRenderer(scene, 64, 40, [0] * 8)       # strips thinner than the halo
 
 
+def test_multi_reset_every_frame_like_a_moving_reference_camera(gpu):
+    """The reference's host loop with a moving camera: frame_count = 0 before EVERY frame the camera moves (state.rs:152; INTEGRATION.md section 4:
+    frt_multi_renderer_reset with motion_halo_rows = K). T-merge still reprojects into the previous frame's spatial reservoirs up to K rows
+    outside the strip (restir.wgsl:846-900 uses frame_count for the seed only), so the "pre" rows must travel although frame_count says 0
+    (they were gated on frame_count and the strip-boundary pixels read stale halo rows)."""
+    frt = gpu
+    import _scenes
+    W, H, N, K = 320, 192, 7, 8
+    scene = frt.scenes.create_cornell_box()
+    cams = _scenes.moving_camera_uniforms(frt, W / H, scene.num_lights, N)
+    one = frt.Renderer(scene, W, H, flags=frt.FLAG_PIPELINE)
+    multi = frt.MultiRenderer(scene, W, H, [0, 0, 0], motion_halo=K)
+    for f in range(N):
+        if f not in (0, 5):          # "camera moved" (the counter runs on over frames 4 -> 5: both forms in one sequence)
+            one.reset(); multi.reset()
+        cams[f].frame_count = one.frame_count
+        assert multi.frame_count == one.frame_count
+        one.render(cams[f]); multi.render(cams[f])
+        got, want = _read_all(frt, multi), _read_all(frt, one)
+        for k in got:
+            assert got[k].tobytes() == want[k].tobytes(), f"frame {f}: {k} differs"
+    assert multi.stats()["halo_overflow"] == 0
+
+
+@pytest.mark.parametrize("strip,step", [(1, 0), (2, 1), (0, 1)])
+def test_multi_strip_failure_latches_until_clear(gpu, strip, step):
+    """A strip whose step fails leaves the other strips with a half-enqueued frame (their T-merge is in flight, `frame_open`): the handle must refuse
+    further frames (FRT_ERR_STATE) instead of re-running step A on them, and frt_multi_renderer_clear must bring every strip back to the state right
+    after create — the frames rendered afterwards equal a fresh single renderer's bit for bit."""
+    frt = gpu
+    W, H = 240, 160
+    scene = frt.scenes.create_cornell_box()
+    cams = [frt.CameraController().build_uniform(W / H, f, scene.num_lights) for f in range(4)]
+    multi = frt.MultiRenderer(scene, W, H, [0, 0, 0])
+    multi.render(cams[0]); multi.render(cams[1])
+    multi.inject_failure(strip, step)
+    with pytest.raises(frt.FrtError, match="injected failure"):
+        multi.render(cams[2])
+    assert multi.frame_count == 2                      # the failed frame did not count
+    for call in (lambda: multi.render(cams[2]), multi.reset, multi.read_display):
+        with pytest.raises(frt.FrtError, match="frt_multi_renderer_clear"):
+            call()
+    multi.clear()
+    assert multi.frame_count == 0
+    one = frt.Renderer(scene, W, H, flags=frt.FLAG_PIPELINE)
+    for f in range(4):
+        one.render(cams[f]); multi.render(cams[f])
+    got, want = _read_all(frt, multi), _read_all(frt, one)
+    for k in got:
+        assert got[k].tobytes() == want[k].tobytes(), k
+    s1, sm = one.stats(), multi.stats()
+    assert (sm["rays_closest"], sm["rays_any"], sm["frames"]) == (s1["rays_closest"], s1["rays_any"], 4)
+
+
+def test_multi_gather_on_the_device(gpu):
+    """frt_multi_renderer_gather: the strips' rows land in ONE device buffer (peer copies on the strips' copy streams, no host staging), ordered
+    behind the frames enqueued so far and in front of the caller's stream; the next frame's writers wait for the copies."""
+    frt = gpu
+    import torch
+    W, H, N = 320, 200, 5
+    scene = frt.scenes.create_cornell_box()
+    cams = [frt.CameraController().build_uniform(W / H, f, scene.num_lights) for f in range(N + 1)]
+    one = frt.Renderer(scene, W, H, flags=frt.FLAG_PIPELINE)
+    multi = frt.MultiRenderer(scene, W, H, [0, 0, 0, 0])
+    disp = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0")
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    side = torch.cuda.Stream()
+    for f in range(N):
+        one.render(cams[f]); multi.render(cams[f])
+    multi.gather(frt.BUF_DISPLAY, 0, 0, disp.data_ptr(), stream=side.cuda_stream)      # asynchronous: `side` is ordered behind the copies
+    multi.gather(frt.BUF_ACCUM, (N - 1) & 1, 0, acc.data_ptr(), stream=side.cuda_stream)
+    multi.render(cams[N]); one.render(cams[N])            # the next frame is enqueued while the rows may still be travelling
+    side.synchronize()
+    want = frt.Renderer(scene, W, H, flags=frt.FLAG_PIPELINE)
+    for f in range(N):
+        want.render(cams[f])
+    assert np.array_equal(disp.cpu().numpy(), want.read_display())
+    assert np.array_equal(acc.cpu().numpy(), want.read_accum())
+    assert np.array_equal(multi.read_display(), one.read_display()) and np.array_equal(multi.read_accum(), one.read_accum())
+    pa = multi.peer_access()
+    assert pa == {"neighbour_pairs_on_different_devices": 0, "pairs_with_peer_access": 0}      # every strip on ordinal 0 here
+    with pytest.raises(frt.FrtError):
+        multi.gather(frt.BUF_DISPLAY, 0, 99, disp.data_ptr())
+
+
+def test_multi_jitter_is_refused_for_strips(gpu):
+    frt = gpu
+    scene = frt.scenes.create_cornell_box()
+    multi = frt.MultiRenderer(scene, 160, 96, [0, 0])
+    multi.set_jitter(0.0, 0.0)
+    with pytest.raises(frt.FrtError, match="strips"):
+        multi.set_jitter(0.25, -0.25)
+    single = frt.MultiRenderer(scene, 160, 96, [0])
+    single.set_jitter(0.25, -0.25)          # one strip = a whole-frame renderer: jitter is its business
+    cam = frt.CameraController().build_uniform(160 / 96, 0, scene.num_lights)
+    single.render(cam)
+    ref = frt.Renderer(scene, 160, 96, flags=frt.FLAG_PIPELINE)
+    ref.set_jitter(0.25, -0.25); ref.render(cam)
+    assert np.array_equal(single.read_display(), ref.read_display())
+
+
 def test_bench_native_rehearsal_on_one_gpu(gpu):
     """`bench.py --gpus 3 --native`: ONE process, three strip renderers through frt_multi_renderer (all on this box's one GPU), one JSON line."""
     import json, subprocess, sys
