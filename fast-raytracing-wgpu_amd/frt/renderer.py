@@ -170,8 +170,8 @@ class MultiRenderer:
         """Back to the state right after creation on every strip; the way out of the failed state (a strip's step failed mid-frame)."""
         check(lib().frt_multi_renderer_clear(self._h))
 
-    def set_jitter(self, jx, jy):
-        check(lib().frt_multi_renderer_set_jitter(self._h, float(jx), float(jy)))
+    def set_jitter(self, jitter):
+        check(lib().frt_multi_renderer_set_jitter(self._h, float(jitter[0]), float(jitter[1])))
 
     def inject_failure(self, strip, step):
         """Testing: the next render call fails on `strip` in step 0 (T-merge half) or 1 (spatial + post half)."""

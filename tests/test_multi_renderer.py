@@ -188,15 +188,15 @@ def test_multi_jitter_is_refused_for_strips(gpu):
     frt = gpu
     scene = frt.scenes.create_cornell_box()
     multi = frt.MultiRenderer(scene, 160, 96, [0, 0])
-    multi.set_jitter(0.0, 0.0)
+    multi.set_jitter((0.0, 0.0))
     with pytest.raises(frt.FrtError, match="strips"):
-        multi.set_jitter(0.25, -0.25)
+        multi.set_jitter((0.25, -0.25))
     single = frt.MultiRenderer(scene, 160, 96, [0])
-    single.set_jitter(0.25, -0.25)          # one strip = a whole-frame renderer: jitter is its business
+    single.set_jitter((0.25, -0.25))          # one strip = a whole-frame renderer: jitter is its business
     cam = frt.CameraController().build_uniform(160 / 96, 0, scene.num_lights)
     single.render(cam)
     ref = frt.Renderer(scene, 160, 96, flags=frt.FLAG_PIPELINE)
-    ref.set_jitter(0.25, -0.25); ref.render(cam)
+    ref.set_jitter((0.25, -0.25)); ref.render(cam)
     assert np.array_equal(single.read_display(), ref.read_display())
 
 
