@@ -325,6 +325,9 @@ void SceneBuilder::build_gpu_layout() {
     }
     quantize_pair_nodes(*this);
     build_quad_nodes(*this);
+    build_wide8(bvh2, wide8);
+    tri_slots8.clear();
+    if (wide8.ok) { tri_slots8.resize(wide8.tri_order.size()); for (size_t i = 0; i < tri_slots8.size(); ++i) tri_slots8[i] = tri_slots[wide8.tri_order[i]]; }
     // shading records: the instance -> mesh -> index -> attribute chain of gbuffer.wgsl:129-145, flattened per triangle
     shade_tris.assign(tris.size(), ShadeTri{});
     for (size_t id = 0; id < tris.size(); ++id) {

@@ -1,0 +1,214 @@
+// frt_bvh8.hpp — the canonical BVH2 collapsed into 8-WIDE NODES WITH GRID BOXES (host only, deterministic). What frt_trace.hpp: trace8 walks.
+//
+// Why (round 4): a walk is a chain of dependent round trips — node -> node -> leaf — that four waves per SIMD cannot hide, and the quad
+// node's step carries a sorting network and up to three stack pushes. An 8-wide node decides three levels of the binary tree per round trip; its
+// children are visited in an order that depends only on the ray's direction signs (no sort; any-hit rays enter the NEAREST inner child first); a node
+// pushes ONE stack word — the mask of its inner children still to visit — so the stack is as deep as the tree (4 entries for the Cornell Box, 7 for
+// the 246k-triangle colonnade; the quad tree: 22 and 31), which is what frees a traced workgroup's LDS. The layout follows Ylitie, Karras and Laine,
+// "Efficient incoherent ray traversal on GPUs through compressed wide BVHs" (HPG 2017), re-cut for a 64-lane wave, per-lane LDS stacks and this
+// build's leaf format — and for rays that START AND END ON SURFACES: on their 8-bit grid (a step of 1/128 .. 1/255 of the node) the flat box of a
+// wall is inflated to a slab two orders of magnitude thicker than the 0.001 offset of a bounce ray's origin, every ray then tests the triangles it
+// starts on and ends at (tools/bvh_quality.cpp: 4.6 instead of 2.2 triangle tests per incoherent ray on the Cornell Box). The grid here has 16 bits: its
+// step (<= 1/32768 of the node) is below the builder's box padding and the wide tree tests the triangles the binary tree tests (2.2).
+//
+// Node, 32 words = 128 bytes (eight uint4; the plane blocks are read with per-lane offsets chosen by the ray's direction signs, like the quad node's):
+//   w0..w2   origin p (f32 x, y, z): the low corner of the node's grid (= of the union of its children's padded boxes)
+//   w3       ex | ey << 8 | ez << 16 | imask << 24     e*: biased f32 exponent of the per-axis power-of-two grid step (step = bits(e << 23));
+//                                                     imask: slots that hold an INNER child
+//   w4       child_base: index of the first inner child; a node's inner children are contiguous, in slot order (child = base + rank among imask)
+//   w5       tri_base (24 bits) | leafmask << 24       leafmask: slots that hold a LEAF child; tri_base: first triangle slot (tris8) of the node's leaves
+//   w6, w7   meta[8] bytes: for a leaf slot  offset | count << 5  (its triangles: tris8[tri_base + offset .. + count)); 0 otherwise
+//   bytes 32..47  lo.x[8] (u16)   48..63  hi.x[8]   64..79  lo.y[8]   80..95  hi.y[8]   96..111  lo.z[8]   112..127  hi.z[8]
+//            child boxes on the node's grid: lo rounded down, hi rounded up, so a child's grid box contains its (padded) float box: the wide tree
+//            prunes a little less than the binary one and never more (hits do not depend on the tree, frt_trace.hpp)
+// An empty slot has neither mask bit set (trace8 ANDs the slab results with imask | leafmask); its grid box is 65535 .. 0.
+// Slot assignment: a child's slot s encodes where it lies in the node: bit a of s set = on the high side along axis a. A ray whose direction has sign
+// octant `oct` (bit a set = negative component) visits the hit children in increasing s ^ oct: near side first on every axis — Ylitie et al.'s
+// ordering; the assignment that maximises sum(dot(centroid_c - centre, dir(s_c))) is found exactly (an 8 x 8 assignment problem, Kuhn–Munkres).
+// Numbering: breadth-first (the top of the tree is contiguous: the first nodes are what a traced workgroup keeps in LDS).
+// Triangles: their own slot array `tris8` (same 48-byte slots as tri_slots, other order): the triangles of a node's leaf children are contiguous.
+#pragma once
+#include "../../include/frt.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace frt {
+
+static const uint32_t kWide8Words = 32;
+static const uint32_t kWide8MaxNodes = 65536;      // trace8's stack word packs child_base into 16 bits (larger trees keep the quad-node walk)
+
+struct Wide8 {
+    std::vector<uint32_t> words;       // kWide8Words per node
+    std::vector<uint32_t> tri_order;   // tris8[i] = tri_slots[tri_order[i]]
+    std::vector<float> child_boxes;    // host only (tools/bvh_quality.cpp prices the grid against them): per node 8 x (lo.xyz, hi.xyz), the children's float boxes
+    uint32_t stack_need = 0;           // entries of the deepest stack a ray can need (one per level with two or more inner children)
+    uint32_t depth = 0;                // levels of wide nodes
+    uint32_t children = 0;             // sum of child counts (statistics)
+    bool ok = false;                   // false: more than kWide8MaxNodes nodes, or a node whose leaves hold more than 31 + 7 triangles
+};
+
+namespace wide8_detail {
+// Kuhn–Munkres for an n x n cost matrix (minimisation), n <= 8. a[i][j]: cost of giving row i column j. Returns col_of_row.
+inline void assign_min(const double a[8][8], int n, int col_of_row[8]) {
+    const double INF = 1e300;
+    double u[9] = {0}, v[9] = {0};
+    int p[9] = {0}, way[9] = {0};
+    for (int i = 1; i <= n; ++i) {
+        p[0] = i;
+        int j0 = 0;
+        double minv[9]; bool used[9];
+        for (int j = 0; j <= n; ++j) { minv[j] = INF; used[j] = false; }
+        do {
+            used[j0] = true;
+            const int i0 = p[j0];
+            double delta = INF; int j1 = 0;
+            for (int j = 1; j <= n; ++j) if (!used[j]) {
+                const double cur = a[i0 - 1][j - 1] - u[i0] - v[j];
+                if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+                if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+            }
+            for (int j = 0; j <= n; ++j) {
+                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+                else minv[j] -= delta;
+            }
+            j0 = j1;
+        } while (p[j0] != 0);
+        do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
+    }
+    for (int j = 1; j <= n; ++j) if (p[j]) col_of_row[p[j] - 1] = j - 1;
+}
+}   // namespace wide8_detail
+
+// t: canonical BVH2 (children adjacent, behind their parent; boxes padded). Leaves of t index triangle slots [left_first, left_first + count).
+inline void build_wide8(const std::vector<frt_bvh2_node>& t, Wide8& out) {
+    out = Wide8{};
+    if (t.empty()) return;
+    auto half_area = [&](uint32_t ni) {
+        const float dx = t[ni].bmax[0] - t[ni].bmin[0], dy = t[ni].bmax[1] - t[ni].bmin[1], dz = t[ni].bmax[2] - t[ni].bmin[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Kids { uint32_t c[8]; int n; int slot[8]; };
+    // 1. collapse: from the two children of an inner node, the inner child with the largest surface area is replaced by its own two children until the
+    //    node holds eight children or only leaves (the same greedy fold as the quad tree's, frt_bvh.cpp: build_quad_nodes)
+    auto children_of = [&](uint32_t ni) -> Kids {
+        Kids k{};
+        if (t[ni].count > 0) { k.c[0] = ni; k.n = 1; return k; }       // a lone leaf root
+        k.n = 2; k.c[0] = t[ni].left_first; k.c[1] = t[ni].left_first + 1;
+        while (k.n < 8) {
+            int pick = -1; float best = -1.0f;
+            for (int i = 0; i < k.n; ++i) if (t[k.c[i]].count == 0 && half_area(k.c[i]) > best) { best = half_area(k.c[i]); pick = i; }
+            if (pick < 0) break;
+            for (int i = k.n; i > pick + 1; --i) k.c[i] = k.c[i - 1];
+            const uint32_t l = t[k.c[pick]].left_first;
+            k.c[pick] = l; k.c[pick + 1] = l + 1; ++k.n;
+        }
+        return k;
+    };
+    // 2. slots: maximise sum(dot(centroid_c - centre, dir(slot))), dir(s).a = +1 where bit a of s is set, else -1
+    auto assign_slots = [&](uint32_t ni, Kids& k) {
+        double cen[3];
+        for (int a = 0; a < 3; ++a) cen[a] = 0.5 * ((double)t[ni].bmin[a] + (double)t[ni].bmax[a]);
+        double cost[8][8];
+        for (int i = 0; i < 8; ++i)
+            for (int s = 0; s < 8; ++s) {
+                double v = 0.0;
+                if (i < k.n) for (int a = 0; a < 3; ++a) {
+                    const double c = 0.5 * ((double)t[k.c[i]].bmin[a] + (double)t[k.c[i]].bmax[a]) - cen[a];
+                    v += ((s >> a) & 1) ? c : -c;
+                }
+                cost[i][s] = -v;      // (dummy rows cost nothing anywhere)
+            }
+        int col[8];
+        wide8_detail::assign_min(cost, 8, col);
+        for (int i = 0; i < k.n; ++i) k.slot[i] = col[i];
+    };
+    std::vector<uint32_t> order(1, 0u), level(1, 1u);
+    std::vector<Kids> kids;
+    std::vector<uint32_t> base;        // child_base per wide node
+    for (size_t h = 0; h < order.size(); ++h) {
+        Kids k = children_of(order[h]);
+        assign_slots(order[h], k);
+        base.push_back((uint32_t)order.size());
+        // inner children get consecutive numbers in SLOT order
+        for (int s = 0; s < 8; ++s)
+            for (int i = 0; i < k.n; ++i)
+                if (k.slot[i] == s && t[k.c[i]].count == 0) { order.push_back(k.c[i]); level.push_back(level[h] + 1u); }
+        kids.push_back(k);
+        out.depth = std::max(out.depth, level[h]);
+        out.children += (uint32_t)k.n;
+        if (order.size() > kWide8MaxNodes) return;      // out.ok stays false
+    }
+    const size_t N = order.size();
+    out.words.assign(N * kWide8Words, 0u);
+    out.child_boxes.assign(N * 48, 0.0f);
+    std::vector<uint32_t> need(N, 0u);
+    // 3. triangles of the leaf children, node by node, slot by slot; 4. boxes on the node's grid
+    for (size_t h = 0; h < N; ++h) {
+        const Kids& k = kids[h];
+        uint32_t* w = &out.words[h * kWide8Words];
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int i = 0; i < k.n; ++i)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], (double)t[k.c[i]].bmin[a]); hi[a] = std::max(hi[a], (double)t[k.c[i]].bmax[a]); }
+        float p[3]; uint32_t e[3]; double step[3];
+        for (int a = 0; a < 3; ++a) {
+            p[a] = (float)lo[a];
+            if ((double)p[a] > lo[a]) p[a] = std::nextafterf(p[a], -INFINITY);      // (lo is a float already: never taken; kept for boxes that are not)
+            const double ext = std::max(hi[a] - (double)p[a], 1e-30);
+            int ex = (int)std::ceil(std::log2(ext / 65535.0));
+            while (std::ldexp(65535.0, ex) < ext) ++ex;                             // 65535 steps must span the extent
+            ex = std::max(-126, std::min(127, ex));
+            e[a] = (uint32_t)(ex + 127);
+            step[a] = std::ldexp(1.0, ex);
+        }
+        memcpy(&w[0], p, 12);
+        uint32_t imask = 0, leafmask = 0, tri_off = 0;
+        const uint32_t tri_base = (uint32_t)out.tri_order.size();
+        uint8_t meta[8] = {0};
+        uint16_t qlo[3][8], qhi[3][8];
+        for (int s = 0; s < 8; ++s) for (int a = 0; a < 3; ++a) { qlo[a][s] = 65535; qhi[a][s] = 0; }
+        for (int s = 0; s < 8; ++s)
+            for (int i = 0; i < k.n; ++i) {
+                if (k.slot[i] != s) continue;
+                const frt_bvh2_node& c = t[k.c[i]];
+                for (int a = 0; a < 3; ++a) { out.child_boxes[h * 48 + s * 6 + a] = c.bmin[a]; out.child_boxes[h * 48 + s * 6 + 3 + a] = c.bmax[a]; }
+                for (int a = 0; a < 3; ++a) {
+                    double gl = std::floor(((double)c.bmin[a] - (double)p[a]) / step[a]), gh = std::ceil(((double)c.bmax[a] - (double)p[a]) / step[a]);
+                    gl = std::max(0.0, std::min(65535.0, gl)); gh = std::max(0.0, std::min(65535.0, gh));
+                    // the planes behind trace8's distances are p + q * step (q * step is exact in f32: 16 bits times a power of two): they must bracket the float box
+                    while (gl > 0.0 && (float)((double)p[a] + gl * step[a]) > c.bmin[a]) gl -= 1.0;
+                    while (gh < 65535.0 && (float)((double)p[a] + gh * step[a]) < c.bmax[a]) gh += 1.0;
+                    qlo[a][s] = (uint16_t)gl; qhi[a][s] = (uint16_t)gh;
+                }
+                if (c.count > 0) {
+                    if (tri_off > 31u || c.count > 7u) return;      // (meta byte: 5 bits of offset, 3 of count; never with leaves of <= 4 triangles)
+                    leafmask |= 1u << s;
+                    meta[s] = (uint8_t)(tri_off | (c.count << 5));
+                    for (uint32_t j = 0; j < c.count; ++j) out.tri_order.push_back(c.left_first + j);
+                    tri_off += c.count;
+                } else {
+                    imask |= 1u << s;
+                }
+            }
+        w[3] = e[0] | (e[1] << 8) | (e[2] << 16) | (imask << 24);
+        w[4] = base[h];
+        if (tri_base >= (1u << 24)) return;
+        w[5] = tri_base | (leafmask << 24);
+        memcpy(&w[6], meta, 8);
+        for (int a = 0; a < 3; ++a) { memcpy(&w[8 + 8 * a], qlo[a], 16); memcpy(&w[12 + 8 * a], qhi[a], 16); }
+    }
+    // stack need, bottom-up (children have larger indices): a node with two or more inner children leaves one word on the stack while a child is walked
+    for (size_t h = N; h-- > 0;) {
+        const uint32_t* w = &out.words[h * kWide8Words];
+        const uint32_t imask = w[3] >> 24, n_in = (uint32_t)__builtin_popcount(imask);
+        uint32_t deepest = 0;
+        for (uint32_t r = 0; r < n_in; ++r) deepest = std::max(deepest, need[w[4] + r]);
+        need[h] = (n_in >= 2u ? 1u : 0u) + deepest;
+    }
+    out.stack_need = need[0];
+    out.ok = true;
+}
+
+} // namespace frt

@@ -437,6 +437,11 @@ int frt_scene_get(const frt_scene* s, int which, void* out) {
     } break;
     case 8: memcpy(out, b.bvh2.data(), b.bvh2.size() * sizeof(frt_bvh2_node)); break;
     case 9: memcpy(out, b.bvh2_tri_index.data(), b.bvh2_tri_index.size() * 4); break;
+    case 10: memcpy(out, b.quad_nodes.data(), b.quad_nodes.size() * sizeof(QuadNode)); break;
+    case 11: memcpy(out, b.wide8.words.data(), b.wide8.words.size() * 4); break;
+    case 12: memcpy(out, b.tri_slots8.data(), b.tri_slots8.size() * sizeof(TriSlot)); break;
+    case 13: memcpy(out, b.tri_slots.data(), b.tri_slots.size() * sizeof(TriSlot)); break;
+    case 14: memcpy(out, b.wide8.child_boxes.data(), b.wide8.child_boxes.size() * 4); break;
     default: return fail(FRT_ERR_INVALID_ARG, "get: unknown selector");
     }
     return FRT_OK;
@@ -444,6 +449,14 @@ int frt_scene_get(const frt_scene* s, int which, void* out) {
 int frt_scene_bvh_stats(const frt_scene* s, uint32_t st[4]) {
     if (!s || !st) return fail(FRT_ERR_INVALID_ARG, "bvh_stats: null");
     st[0] = s->b.bvh_depth; st[1] = s->b.bvh_leaves; st[2] = s->b.bvh_max_leaf; st[3] = (uint32_t)s->b.pair_nodes.size();
+    return FRT_OK;
+}
+int frt_scene_tree_stats(const frt_scene* s, uint32_t st[8]) {
+    if (!s || !st) return fail(FRT_ERR_INVALID_ARG, "tree_stats: null");
+    const SceneBuilder& b = s->b;
+    st[0] = (uint32_t)b.quad_nodes.size(); st[1] = b.quad_stack_need;
+    st[2] = b.wide8.ok ? (uint32_t)(b.wide8.words.size() / kWide8Words) : 0u; st[3] = b.wide8.stack_need; st[4] = b.wide8.depth; st[5] = b.wide8.children;
+    st[6] = (uint32_t)b.tri_slots8.size(); st[7] = 0u;
     return FRT_OK;
 }
 void frt_camera_default(float aspect, uint32_t frame_count, uint32_t num_lights, frt_camera_uniform* out) {

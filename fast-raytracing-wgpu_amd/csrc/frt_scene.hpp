@@ -3,6 +3,7 @@
 // explicit host SAH-BVH over the flattened world-space triangle list.
 #pragma once
 #include "../../include/frt.h"
+#include "frt_bvh8.hpp"
 #include <vector>
 #include <string>
 #include <stdint.h>
@@ -113,6 +114,8 @@ public:
     std::vector<uint32_t> qnode_a, qnode_b;     // quantized pair nodes, 4 words per node each (frt_trace.hpp: QBvh)
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     std::vector<TriSlot> tri_slots;
+    Wide8 wide8;                            // the same tree as 8-wide compressed nodes (frt_bvh8.hpp; frt_trace.hpp: trace8); wide8.ok = false: not walkable that way
+    std::vector<TriSlot> tri_slots8;        // the triangle slots in the wide tree's order (a node's leaf triangles contiguous)
     std::vector<ShadeTri> shade_tris;
     std::vector<InstanceDev> instances_dev;
     float srgb_lut[256];

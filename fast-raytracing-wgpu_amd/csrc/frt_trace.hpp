@@ -49,6 +49,9 @@ struct SceneView {
     uint32_t bvh_depth;
     uint32_t num_nodes4;        // quad nodes (in the padding before the pointer below)
     const float4* nodes4;       // quad nodes, 8 x float4 each (frt_bvh.cpp: build_quad_nodes): what the default kernels walk (trace4)
+    const uint4* nodes8;        // 8-wide nodes with 16-bit grid boxes, 8 x uint4 each (frt_bvh8.hpp; trace8), or null: the scene has no such tree
+    const float4* tris8;        // the triangle slots in that tree's order
+    uint32_t num_nodes8, stack_need8;
 };
 
 struct HitRec {
@@ -332,6 +335,131 @@ FRT_HD void trace4(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, uint
         for (uint32_t kk = 2u; kk < count; ++kk) if (test(first + kk)) return;
         if (!more) break;
         top -= stride; cur = next;
+    }
+    if (!ANY && hit.tri != 0xFFFFFFFFu) {
+        bool front = best_det > 0.0f;
+        if (sc.instances[hit.inst].flip) front = !front;
+        hit.front = front;
+    }
+}
+
+
+// ---- 8-wide nodes with grid boxes (frt_bvh8.hpp) -------------------------------------------------------------------------------------------
+// One node step decides three levels of the binary tree: eight slab tests on planes reconstructed from 16-bit grid coordinates (t = q * (step / d) +
+// (p - o) / d: one conversion and one fma per plane, the near / far plane blocks picked by the ray's direction signs at load time like the quad
+// node's), the hit children split into LEAF children — tested next, one leaf child (<= 2 triangles, fetched together) per leaf step — and INNER
+// children, of which one is entered and the others wait on the stack as ONE word, (child base << 16) | (inner mask << 8) | (mask still to visit).
+// Order of the inner children: increasing slot ^ octant (the builder put a child into the slot that says on which side of the node it lies, so this
+// is near side first on every axis; no sort); an any-hit ray enters the NEAREST hit inner child first, exactly (it only has to find an occluder: in the
+// host model of a wave's lockstep walk, tools/bvh_quality.cpp, 2.9 + 1.8 node + leaf steps per shadow wave-ray instead of 6.6 + 3.3 in octant order —
+// the quad tree: 6.8 + 1.8 — while a bounce ray's 5.7 + 4.6 — quad tree 10.7 + 3.9 — do not depend on it). Same hits as every other walk (hit
+// semantics at the top of this file; the grid boxes contain the float boxes).
+// The stack holds one word per level with two or more inner children hit: kStack8 entries cover every tree the renderer hands to this walk
+// (SceneView::stack_need8; a deeper tree keeps the quad walk, frt_renderer.hip).
+static const int kStack8 = 8;
+FRT_HD uint32_t ctz32(uint32_t x) { return (uint32_t)__builtin_ctz(x); }
+FRT_HD uint32_t popc32(uint32_t x) { return (uint32_t)__builtin_popcount(x); }
+// the set bit s of the 8-bit mask m (non-zero) with the smallest s ^ octant; om = A0 | A1 << 8 | A2 << 16, A_k = the slots whose bit k equals the octant's
+FRT_HD uint32_t pick_octant(uint32_t m, uint32_t om) {
+    uint32_t t = m & (om >> 16); m = t ? t : m;
+    t = m & (om >> 8); m = t ? t : m;
+    t = m & om; m = t ? t : m;
+    return ctz32(m);
+}
+FRT_HD float half_lo(uint32_t w) { return (float)(w & 0xFFFFu); }      // (v_cvt_f32_u32 with an SDWA word select: one instruction each)
+FRT_HD float half_hi(uint32_t w) { return (float)(w >> 16); }
+// NODES: the node array's address space is the caller's business — `nb` points at node 0 (HBM, or a workgroup's LDS copy of the whole tree).
+template <bool ANY>
+FRT_HD void trace8(const SceneView& sc, const char* nb, f3 o, f3 d, float tmin, float tmax, uint32_t* stk, uint32_t stride, HitRec& hit) {
+    hit.t = tmax; hit.tri = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f; hit.inst = 0u; hit.front = false;
+    float best_det = 0.0f;
+    const f3 inv = mk3(prune_rcp(d.x), prune_rcp(d.y), prune_rcp(d.z));
+    const uint32_t nxo = 32u | ((f2u(d.x) >> 31) << 4), nyo = 64u | ((f2u(d.y) >> 31) << 4), nzo = 96u | ((f2u(d.z) >> 31) << 4);      // near plane blocks; far = ^ 16
+    const uint32_t oct = (f2u(d.x) >> 31) | ((f2u(d.y) >> 31) << 1) | ((f2u(d.z) >> 31) << 2);
+    const uint32_t om = (0x55u << (oct & 1u)) | ((0x33u << (oct & 2u)) << 8) | ((0x0Fu << (oct & 4u)) << 16);
+    const uint32_t kNone = 0xFFFFFFFFu;
+    uint32_t* top = stk;           // next free stack entry
+    uint32_t cur = 0u;             // the node to step next (node 0 is the root), or kNone
+    uint32_t T = 0u, meta0 = 0u, meta1 = 0u;      // leaf children still to test: (tri_base << 8) | mask, and the node's meta bytes
+    // the next node from the stack: the topmost word's next child in octant order; the word stays while it has children left
+    auto from_stack = [&]() {
+        if (top == stk) { cur = kNone; return; }
+        uint32_t g = *(top - stride);
+        const uint32_t s = pick_octant(g & 0xFFu, om);
+        cur = (g >> 16) + popc32((g >> 8) & ((1u << s) - 1u) & 0xFFu);
+        g &= ~(1u << s);
+        if (g & 0xFFu) *(top - stride) = g; else top -= stride;
+    };
+    for (;;) {
+        while (T == 0u && cur != kNone) {
+            const uint32_t noff = cur << 7;
+            const uint4 h0 = *reinterpret_cast<const uint4*>(nb + noff), h1 = *reinterpret_cast<const uint4*>(nb + (noff + 16u));
+            const uint4 qnx = *reinterpret_cast<const uint4*>(nb + (noff | nxo)), qfx = *reinterpret_cast<const uint4*>(nb + (noff | (nxo ^ 16u)));
+            const uint4 qny = *reinterpret_cast<const uint4*>(nb + (noff | nyo)), qfy = *reinterpret_cast<const uint4*>(nb + (noff | (nyo ^ 16u)));
+            const uint4 qnz = *reinterpret_cast<const uint4*>(nb + (noff | nzo)), qfz = *reinterpret_cast<const uint4*>(nb + (noff | (nzo ^ 16u)));
+            const float sx = u2f((h0.w & 0xFFu) << 23) * inv.x, sy = u2f(((h0.w >> 8) & 0xFFu) << 23) * inv.y, sz = u2f(((h0.w >> 16) & 0xFFu) << 23) * inv.z;
+            const float bx = (u2f(h0.x) - o.x) * inv.x, by = (u2f(h0.y) - o.y) * inv.y, bz = (u2f(h0.z) - o.z) * inv.z;
+            const float tlim = ANY ? tmax : hit.t;
+            const uint32_t imask = h0.w >> 24, leafmask = h1.y >> 24;
+            const uint32_t wnx[4] = {qnx.x, qnx.y, qnx.z, qnx.w}, wfx[4] = {qfx.x, qfx.y, qfx.z, qfx.w};
+            const uint32_t wny[4] = {qny.x, qny.y, qny.z, qny.w}, wfy[4] = {qfy.x, qfy.y, qfy.z, qfy.w};
+            const uint32_t wnz[4] = {qnz.x, qnz.y, qnz.z, qnz.w}, wfz[4] = {qfz.x, qfz.y, qfz.z, qfz.w};
+            uint32_t hits = 0u, kmin = 0xFFFFFFFFu;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int w = c >> 1;
+                const float nx = (c & 1) ? half_hi(wnx[w]) : half_lo(wnx[w]), fx = (c & 1) ? half_hi(wfx[w]) : half_lo(wfx[w]);
+                const float ny = (c & 1) ? half_hi(wny[w]) : half_lo(wny[w]), fy = (c & 1) ? half_hi(wfy[w]) : half_lo(wfy[w]);
+                const float nz = (c & 1) ? half_hi(wnz[w]) : half_lo(wnz[w]), fz = (c & 1) ? half_hi(wfz[w]) : half_lo(wfz[w]);
+                const float tn = fmaxn(fmaxn(__builtin_fmaf(nx, sx, bx), __builtin_fmaf(ny, sy, by)), fmaxn(__builtin_fmaf(nz, sz, bz), tmin));
+                const float tf = fminn(fminn(__builtin_fmaf(fx, sx, bx), __builtin_fmaf(fy, sy, by)), fminn(__builtin_fmaf(fz, sz, bz), tlim));
+                // (no slack factor: the host pads every box by 1e-4 of the scene extent, four hundred times the rounding of these fma; slab4)
+                const bool h = tn <= tf;
+                hits |= h ? (1u << c) : 0u;
+                if (ANY) {      // the nearest hit INNER child: entry distance (> 0, so its bits order like the float) with the slot in the three lowest bits
+                    const uint32_t key = (h && ((imask >> c) & 1u)) ? ((f2u(tn) & ~7u) | (uint32_t)c) : 0xFFFFFFFFu;
+                    kmin = key < kmin ? key : kmin;
+                }
+            }
+            const uint32_t ih = hits & imask;
+            T = hits & leafmask;
+            if (T) { T |= h1.y << 8; meta0 = h1.z; meta1 = h1.w; }
+            if (ih) {
+                const uint32_t s = ANY ? (kmin & 7u) : pick_octant(ih, om);
+                cur = h1.x + popc32(imask & ((1u << s) - 1u));
+                const uint32_t rem = ih & ~(1u << s);
+                if (rem) { *top = (h1.x << 16) | (imask << 8) | rem; top += stride; }
+            } else if (T) cur = kNone;      // (the stack is looked at after this node's leaves)
+            else from_stack();
+        }
+        if (T == 0u) break;      // nothing to step, nothing on the stack
+        // one leaf child of the node stepped last: its (one or two) triangles fetched together, like trace4's leaf step
+        {
+            const uint32_t lh = T & 0xFFu;
+            const uint32_t s = ANY ? pick_octant(lh, om) : ctz32(lh);
+            T &= ~(1u << s);
+            const uint32_t meta = ((s & 4u) ? meta1 : meta0) >> ((s & 3u) << 3);
+            const uint32_t first = (T >> 8) + (meta & 31u), count = (meta >> 5) & 7u;
+            auto test3 = [&](float4 a, float4 b, float4 c) -> bool {
+                float t, u, v, det;
+                if (intersect_tri(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), o, d, tmin, tmax, t, u, v, det)) {
+                    uint32_t id = f2u(a.w);
+                    if (ANY) { hit.tri = id; hit.t = t; return true; }
+                    if (t < hit.t || (t == hit.t && id < hit.tri)) {
+                        hit.t = t; hit.u = u; hit.v = v; hit.tri = id; hit.inst = f2u(b.w); best_det = det;
+                    }
+                }
+                return false;
+            };
+            const float4* tp = sc.tris8 + (size_t)first * 3u;
+            const float4 a0 = tp[0], b0 = tp[1], c0 = tp[2];
+            float4 a1 = a0, b1 = b0, c1 = c0;
+            if (count > 1u) { a1 = tp[3]; b1 = tp[4]; c1 = tp[5]; }
+            if (test3(a0, b0, c0)) return;
+            if (count > 1u && test3(a1, b1, c1)) return;
+            for (uint32_t kk = 2u; kk < count; ++kk) { const float4* tq = tp + (size_t)kk * 3u; if (test3(tq[0], tq[1], tq[2])) return; }
+            if ((T & 0xFFu) == 0u) { T = 0u; if (cur == kNone) from_stack(); }
+        }
     }
     if (!ANY && hit.tri != 0xFFFFFFFFu) {
         bool front = best_det > 0.0f;

@@ -96,6 +96,7 @@ SYMBOLS = {
     "frt_scene_counts": (C.c_int, [_P, _P]),
     "frt_scene_get": (C.c_int, [_P, C.c_int, _P]),
     "frt_scene_bvh_stats": (C.c_int, [_P, _P]),
+    "frt_scene_tree_stats": (C.c_int, [_P, _P]),
     "frt_camera_default": (None, [C.c_float, _U32, _U32, C.POINTER(CameraUniform)]),
     "frt_camera_build_uniform": (C.c_int, [_P, C.c_float, C.c_float, _P, C.c_float, _U32, _U32, _P, C.POINTER(CameraUniform), _P]),
     "frt_camera_halton_jitter": (None, [_U32, _U32, _U32, C.c_float, _P]),

@@ -94,8 +94,20 @@ class SceneBuilder:
     def num_lights(self):
         return self.counts()["lights"]
 
+    def tree_stats(self):
+        s = (C.c_uint32 * 8)()
+        check(lib().frt_scene_tree_stats(self._h, s))
+        return dict(zip(("quad_nodes", "quad_stack_need", "wide8_nodes", "wide8_stack_need", "wide8_depth", "wide8_children", "wide8_tri_slots"), list(s)))
+
     def get(self, what):
         n = self.counts()
+        if what in ("quad_nodes", "wide8_nodes", "tri_slots8", "tri_slots"):
+            t = self.tree_stats()
+            which, shape, dt = {"quad_nodes": (10, (t["quad_nodes"], 32), np.float32), "wide8_nodes": (11, (t["wide8_nodes"], 20), np.uint32),
+                                "tri_slots8": (12, (t["wide8_tri_slots"], 12), np.float32), "tri_slots": (13, (n["tris"], 12), np.float32)}[what]
+            out = np.zeros(shape, dt)
+            check(lib().frt_scene_get(self._h, which, out.ctypes.data))
+            return out
         spec = {"tris": (0, (n["tris"], 9), np.float32), "tri_instance": (1, (n["tris"],), np.uint32),
                 "materials": (2, (n["materials"], 16), np.uint32), "lights": (3, (n["lights"], 16), np.uint32),
                 "attributes": (4, (n["attributes"], 8), np.float32), "indices": (5, (n["indices"],), np.uint32),

@@ -135,8 +135,14 @@ frt_scene* frt_scene_create_gltf_scene(const char* path, const float model_trans
 /* Introspection (tests): counts[8] = tris, instances, materials, lights, meshes, attributes, indices, bvh2 nodes */
 int frt_scene_counts(const frt_scene* s, uint32_t counts[8]);
 /* which: 0 tris (9 f32: v0,e1,e2), 1 tri_instance (u32), 2 materials, 3 lights, 4 attributes, 5 indices, 6 mesh infos (16 B),
- * 7 instances (120 B: mesh,mat,first_tri,tri_count,flip u32; m[16]; w2o[9] f32), 8 bvh2 nodes (32 B), 9 bvh2 tri_index (u32) */
+ * 7 instances (120 B: mesh,mat,first_tri,tri_count,flip u32; m[16]; w2o[9] f32), 8 bvh2 nodes (32 B), 9 bvh2 tri_index (u32);
+ * the device forms of the tree (frt_scene_tree_stats gives the counts): 10 quad nodes (128 B), 11 8-wide compressed nodes (80 B, csrc/frt_bvh8.hpp),
+ * 12 triangle slots in the 8-wide tree's order (48 B: v0, id; e1, instance; e2, 0), 13 triangle slots in BVH2 leaf order (48 B),
+ * 14 the float boxes behind the 8-wide nodes' grid boxes (192 B per node: 8 x lo.xyz, hi.xyz; host data for tools/bvh_quality.cpp) */
 int frt_scene_get(const frt_scene* s, int which, void* out);
+/* stats[8]: quad nodes, deepest traversal stack of the quad tree, 8-wide nodes (0: the scene has no 8-wide tree: more than 65,536 nodes), deepest stack of
+ * the 8-wide tree, its levels, sum of its nodes' child counts, its triangle slots, 0 */
+int frt_scene_tree_stats(const frt_scene* s, uint32_t stats[8]);
 /* bvh stats[4]: max depth, leaves, max leaf size, wide-node count */
 int frt_scene_bvh_stats(const frt_scene* s, uint32_t stats[4]);
 

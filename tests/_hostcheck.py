@@ -17,6 +17,7 @@ class HostCheck:
         L.hc_set_jitter.argtypes = [P, C.c_float, C.c_float]
         L.hc_trace.argtypes = [P, C.c_int, U32, P, P, C.c_float, P, P, P, P, P, C.c_int]
         L.hc_quad_stats.argtypes = [P, P]
+        L.hc_wide8_stats.argtypes = [P, P]
 
     def renderer(self, scene, w, h, max_depth=8, nthreads=8, state_machine=False):
         return HcRenderer(self, scene, w, h, max_depth, nthreads, state_machine)
@@ -26,7 +27,13 @@ class HostCheck:
         self.L.hc_quad_stats(scene._h, out)
         return dict(zip(("nodes", "stack_need", "stack_walked", "leaves", "triangles", "children_x100"), list(out)))
 
+    def wide8_stats(self, scene):
+        out = (C.c_uint32 * 8)()
+        self.L.hc_wide8_stats(scene._h, out)
+        return dict(zip(("nodes", "stack_need", "stack_walked", "leaves", "triangles", "children_x100", "defects", "levels"), list(out)))
+
     def trace(self, scene, o, d, tmin, tmax, any_hit=False, quantized=False):
+        """quantized: False pair nodes (trace), True 16-bit pair nodes (trace_q), 2 quad nodes (trace4), 3 8-wide nodes with grid boxes (trace8)"""
         o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32); n = o.shape[0]
         tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float32), (n,)))
         t = np.zeros(n, np.float32); tri = np.zeros(n, np.uint32); uv = np.zeros((n, 2), np.float32); fr = np.zeros(n, np.uint8)

@@ -97,6 +97,9 @@ void* hc_create(const frt_scene* s, uint32_t W, uint32_t H, uint32_t max_depth, 
     sv.nodes = reinterpret_cast<const float4*>(b.pair_nodes.data());
     sv.nodes4 = reinterpret_cast<const float4*>(b.quad_nodes.data());
     sv.tris = reinterpret_cast<const float4*>(b.tri_slots.data());
+    sv.nodes8 = b.wide8.ok ? reinterpret_cast<const uint4*>(b.wide8.words.data()) : nullptr;
+    sv.tris8 = reinterpret_cast<const float4*>(b.tri_slots8.data());
+    sv.num_nodes8 = b.wide8.ok ? (uint32_t)(b.wide8.words.size() / kWide8Words) : 0u; sv.stack_need8 = b.wide8.stack_need;
     sv.shade_tris = reinterpret_cast<const float4*>(b.shade_tris.data());
     sv.instances = reinterpret_cast<const InstanceView*>(b.instances_dev.data());
     sv.mesh_infos = reinterpret_cast<const MeshInfoView*>(b.mesh_infos.data());
@@ -195,6 +198,9 @@ void hc_trace(const frt_scene* s, int any, uint32_t n, const float* o, const flo
     sv.nodes = reinterpret_cast<const float4*>(b.pair_nodes.data());
     sv.nodes4 = reinterpret_cast<const float4*>(b.quad_nodes.data());
     sv.tris = reinterpret_cast<const float4*>(b.tri_slots.data());
+    sv.nodes8 = b.wide8.ok ? reinterpret_cast<const uint4*>(b.wide8.words.data()) : nullptr;
+    sv.tris8 = reinterpret_cast<const float4*>(b.tri_slots8.data());
+    sv.num_nodes8 = b.wide8.ok ? (uint32_t)(b.wide8.words.size() / kWide8Words) : 0u; sv.stack_need8 = b.wide8.stack_need;
     sv.instances = reinterpret_cast<const InstanceView*>(b.instances_dev.data());
     QBvh qb;
     qb.a = reinterpret_cast<const uint4*>(b.qnode_a.data()); qb.b = reinterpret_cast<const uint4*>(b.qnode_b.data()); qb.tris = sv.tris;
@@ -203,7 +209,11 @@ void hc_trace(const frt_scene* s, int any, uint32_t n, const float* o, const flo
     for (uint32_t i = 0; i < n; ++i) {
         HitRec h;
         f3 oo = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-        if (quantized == 2) { if (any) trace4<true>(sv, oo, dd, tmin, tmax[i], stack, 1u, h); else trace4<false>(sv, oo, dd, tmin, tmax[i], stack, 1u, h); }
+        if (quantized == 3) {      // the 8-wide nodes with grid boxes (frt_trace.hpp: trace8)
+            const char* nb = reinterpret_cast<const char*>(sv.nodes8);
+            if (any) trace8<true>(sv, nb, oo, dd, tmin, tmax[i], stack, 1u, h); else trace8<false>(sv, nb, oo, dd, tmin, tmax[i], stack, 1u, h);
+        }
+        else if (quantized == 2) { if (any) trace4<true>(sv, oo, dd, tmin, tmax[i], stack, 1u, h); else trace4<false>(sv, oo, dd, tmin, tmax[i], stack, 1u, h); }
         else if (quantized) { if (any) trace_q<true>(sv, qb, oo, dd, tmin, tmax[i], stack, 1u, h); else trace_q<false>(sv, qb, oo, dd, tmin, tmax[i], stack, 1u, h); }
         else if (any) trace<true>(sv, oo, dd, tmin, tmax[i], stack, 1u, h);
         else trace<false>(sv, oo, dd, tmin, tmax[i], stack, 1u, h);
@@ -237,6 +247,50 @@ void hc_quad_stats(const frt_scene* s, uint32_t out[6]) {
         }
     }
     out[5] = (uint32_t)(kids * 100u / b.quad_nodes.size());
+}
+
+// probe: the 8-wide tree (frt_bvh8.hpp). out = {nodes, stack need reported by the builder, stack need found by walking every root-to-leaf path with all
+// inner children hit, leaf children reached, triangle slots covered by them, children per node x 100, grid boxes that do not contain their child's float box, levels}
+void hc_wide8_stats(const frt_scene* s, uint32_t out[8]) {
+    const SceneBuilder& b = s->b;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!b.wide8.ok) return;
+    const std::vector<uint32_t>& w = b.wide8.words;
+    out[0] = (uint32_t)(w.size() / kWide8Words); out[1] = b.wide8.stack_need;
+    struct Item { uint32_t node, used, level; };
+    std::vector<Item> todo(1, Item{0u, 0u, 1u});
+    std::vector<uint8_t> seen(b.tri_slots8.size(), 0);
+    uint64_t kids = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back(); todo.pop_back();
+        const uint32_t* n = &w[(size_t)it.node * kWide8Words];
+        const uint32_t imask = n[3] >> 24, leafmask = n[5] >> 24, tri_base = n[5] & 0xFFFFFFu;
+        if (imask & leafmask) out[6] += 1000000u;      // a slot cannot be both
+        const uint32_t n_in = (uint32_t)__builtin_popcount(imask);
+        kids += n_in + (uint32_t)__builtin_popcount(leafmask);
+        out[7] = std::max(out[7], it.level);
+        float p[3]; memcpy(p, n, 12);
+        const uint16_t* q = reinterpret_cast<const uint16_t*>(&n[8]);
+        const uint8_t* meta = reinterpret_cast<const uint8_t*>(&n[6]);
+        const uint32_t used = it.used + (n_in >= 2u ? 1u : 0u);
+        out[2] = std::max(out[2], used);
+        uint32_t rank = 0;
+        for (int c = 0; c < 8; ++c) {
+            if (!(((imask | leafmask) >> c) & 1u)) continue;
+            for (int a = 0; a < 3; ++a) {      // the planes trace8 stands on bracket the child's float box
+                const float step = u2f(((n[3] >> (8 * a)) & 0xFFu) << 23);
+                const float lo = p[a] + (float)q[16 * a + c] * step, hi = p[a] + (float)q[16 * a + 8 + c] * step;
+                if (!(lo <= b.wide8.child_boxes[(size_t)it.node * 48 + c * 6 + a] && hi >= b.wide8.child_boxes[(size_t)it.node * 48 + c * 6 + 3 + a])) out[6] += 1u;
+            }
+            if ((imask >> c) & 1u) { todo.push_back(Item{n[4] + rank, used, it.level + 1u}); ++rank; }
+            else {
+                out[3] += 1u;
+                const uint32_t first = tri_base + (meta[c] & 31u), cnt = meta[c] >> 5;
+                for (uint32_t k = 0; k < cnt; ++k) { if (first + k < seen.size() && !seen[first + k]) { seen[first + k] = 1; out[4] += 1u; } else out[6] += 1000u; }
+            }
+        }
+    }
+    out[5] = (uint32_t)(kids * 100u / std::max<size_t>(w.size() / kWide8Words, 1));
 }
 
 } // extern "C"

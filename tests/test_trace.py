@@ -48,14 +48,15 @@ def test_bvh_equals_bruteforce(frt, orc, hostcheck, which):
         th, ih, uvh, fh = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=False)   # product traversal (pair nodes), host build
         tq, iq, uvq, fq = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=False, quantized=True)   # ... over the 16-bit pair nodes of the resident kernels
         t4, i4, uv4, f4 = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=False, quantized=2)      # ... over the quad nodes (four children per node)
-        for (t, i, uv, f) in ((tv, iv, uvv, fv), (th, ih, uvh, fh), (tq, iq, uvq, fq), (t4, i4, uv4, f4)):
+        t8, i8, uv8, f8 = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=False, quantized=3)      # ... over the 8-wide nodes with grid boxes (trace8)
+        for (t, i, uv, f) in ((tv, iv, uvv, fv), (th, ih, uvh, fh), (tq, iq, uvq, fq), (t4, i4, uv4, f4), (t8, i8, uv8, f8)):
             assert np.array_equal(i, ib) and np.array_equal(t, tb)
             hit = ib != 0xFFFFFFFF
             assert np.array_equal(uv[hit], uvb[hit]) and np.array_equal(f[hit], fb[hit])
         assert (ib != 0xFFFFFFFF).mean() > (0.2 if tmax > 1 else 0.02)
         ob = os_.trace_any(o, d, tmin, tmax, False)
         assert np.array_equal(os_.trace_any(o, d, tmin, tmax, True), ob)
-        for quantized in (False, True, 2):
+        for quantized in (False, True, 2, 3):
             _, ia, _, _ = hostcheck.trace(fs, o, d, tmin, tmax, any_hit=True, quantized=quantized)
             assert np.array_equal((ia != 0xFFFFFFFF).astype(np.uint8), ob)
         assert np.array_equal(ob.astype(bool), tb >= 0)                           # any-hit <=> a closest hit exists
@@ -69,7 +70,7 @@ def test_in_plane_reconnection_rays_are_not_lost(frt, orc, hostcheck):
     d = np.array([[-0.76039785, 0, -0.64945745], [-0.08538333, 0, -0.9963482], [-0.3049969, 0, -0.95235336], [-0.8957124, 0, -0.4446341]], np.float32)
     tmax = np.array([0.32927045, 0.03921813, 0.026023595, 0.24082603], np.float32)
     want = os_.trace_any(o, d, 0.0001, tmax, False)
-    for quantized in (False, True, 2):
+    for quantized in (False, True, 2, 3):
         _, tri, _, _ = hostcheck.trace(fs, o, d, 0.0001, tmax, any_hit=True, quantized=quantized)
         assert np.array_equal((tri != 0xFFFFFFFF).astype(np.uint8), want)
 
@@ -138,6 +139,30 @@ def test_quad_tree_covers_the_scene_and_fits_the_stack(frt, hostcheck):
     t2, i2, _, _ = hostcheck.trace(deep, o, d.astype(np.float32), 0.0, 3e38, any_hit=False)
     t4, i4, _, _ = hostcheck.trace(deep, o, d.astype(np.float32), 0.0, 3e38, any_hit=False, quantized=2)
     assert np.array_equal(i2, i4) and np.array_equal(t2, t4) and (i2 != 0xFFFFFFFF).mean() > 0.2
+    # the 8-wide tree of the same lopsided scene (coordinates over 36 binary orders of magnitude: every node has its own grid)
+    wd = hostcheck.wide8_stats(deep)
+    assert wd["defects"] == 0 and wd["triangles"] == n and wd["stack_walked"] <= wd["stack_need"] <= 8, wd
+    t8, i8, _, _ = hostcheck.trace(deep, o, d.astype(np.float32), 0.0, 3e38, any_hit=False, quantized=3)
+    assert np.array_equal(i2, i8) and np.array_equal(t2, t8)
+
+
+def test_wide8_tree_covers_the_scene_and_needs_a_shallow_stack(frt, hostcheck):
+    """The 8-wide tree with grid boxes (csrc/frt_bvh8.hpp; frt_trace.hpp: trace8): every triangle slot under exactly one leaf child, the same leaves as
+    the binary tree, every grid box containing its child's float box (the planes trace8 reconstructs bracket it: the wide tree may only prune less),
+    inner children numbered contiguously in slot order, and a traversal stack as deep as the TREE (one word per level), not as the sum of its fan-outs."""
+    for make, max_need in ((frt.scenes.create_cornell_box, 5), (frt.scenes.create_restir_scene, 6)):
+        fs = make()
+        w = hostcheck.wide8_stats(fs); b = fs.bvh_stats(); t = fs.tree_stats(); q = hostcheck.quad_stats(fs)
+        assert w["defects"] == 0, w
+        assert w["leaves"] == b["leaves"] and w["triangles"] == fs.counts()["tris"] == t["wide8_tri_slots"]
+        assert w["nodes"] == t["wide8_nodes"] and w["stack_need"] == t["wide8_stack_need"] and w["levels"] == t["wide8_depth"]
+        assert w["stack_walked"] <= w["stack_need"] <= max_need < q["stack_need"]
+        assert w["nodes"] < q["nodes"] * 0.65 and w["children_x100"] > 400
+        # the triangle slots are a permutation of the binary tree's
+        a = fs.get("tri_slots8"); c = fs.get("tri_slots")
+        assert np.array_equal(np.sort(a[:, 3].view(np.uint32)), np.arange(a.shape[0])) and np.array_equal(np.sort(c[:, 3].view(np.uint32)), np.arange(c.shape[0]))
+        order = np.argsort(a[:, 3].view(np.uint32)); order_c = np.argsort(c[:, 3].view(np.uint32))
+        assert a[order].tobytes() == c[order_c].tobytes()
 
 
 def test_heavily_overlapping_geometry_builds_in_bounded_time(frt, hostcheck):
@@ -165,3 +190,8 @@ def test_heavily_overlapping_geometry_builds_in_bounded_time(frt, hostcheck):
     t2, i2, _, _ = hostcheck.trace(scene, o, d, 0.0, 100.0, any_hit=False)
     t4, i4, _, _ = hostcheck.trace(scene, o, d, 0.0, 100.0, any_hit=False, quantized=2)
     assert np.array_equal(i2, i4) and np.array_equal(t2, t4) and (i2 != 0xFFFFFFFF).mean() > 0.5
+    w = hostcheck.wide8_stats(scene)
+    if w["nodes"]:      # (a pile of coincident boxes may need a deeper stack than trace8 has: the renderer then keeps the quad walk)
+        assert w["defects"] == 0 and w["triangles"] == n
+        t8, i8, _, _ = hostcheck.trace(scene, o, d, 0.0, 100.0, any_hit=False, quantized=3)
+        assert np.array_equal(i2, i8) and np.array_equal(t2, t8)

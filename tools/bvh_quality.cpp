@@ -30,6 +30,7 @@ static V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b
 static V3 norm(V3 a) { float l = std::sqrt(dot(a, a)); return l > 0 ? a * (1.0f / l) : a; }
 
 struct Tri { V3 v0, e1, e2; };
+static uint64_t g_dbg[2][4];      // any-hit rays: [quad | 8-wide][unoccluded rays, their triangle tests, occluded rays, theirs]
 struct Quad { float lo[3][4], hi[3][4]; uint32_t ref[4]; int n; };
 static const uint32_t kLeaf = 0x80000000u, kNone = 0xFFFFFFFFu;
 
@@ -163,6 +164,7 @@ struct Lane {
             if (!(v >= 0 && u + v <= 1)) continue;
             float t = dot(tr.e2, qq) * iv;
             if (!(t > tmin && t < tmax)) continue;
+            if (getenv("NOCULL") && any) continue;
             if (any) { hit = id; finish(); return; }
             if (t < best || (t == best && id < hit)) { best = t; hit = id; if (shared_best && t < *shared_best) *shared_best = t; }
         }
@@ -206,7 +208,263 @@ static void run_wave(const Tree& T, std::vector<Lane>& L, const std::vector<char
         }
     }
     uint64_t mx = 0;
-    for (size_t i = 0; i < L.size(); ++i) if (act[i]) { ++w.rays; w.lane_nodes += L[i].node_steps; w.lane_tris += L[i].tri_tests; mx = std::max(mx, L[i].node_steps); }
+    for (size_t i = 0; i < L.size(); ++i) if (act[i]) { ++w.rays; w.lane_nodes += L[i].node_steps; w.lane_tris += L[i].tri_tests; mx = std::max(mx, L[i].node_steps);
+        if (L[i].any) { const int k = L[i].hit != kNone; g_dbg[0][2 * k] += 1; g_dbg[0][2 * k + 1] += L[i].tri_tests; } }
+    w.max_lane_nodes += mx;
+}
+
+
+// ---- the 8-wide compressed tree (csrc/frt_bvh8.hpp) walked the way frt_trace.hpp: trace8 walks it ---------------------------------------------
+// Lane state: G = the group of inner children still to visit of the node stepped last (base, imask, hit mask), T = the hit LEAF children of that node,
+// a stack of G words. A node step takes the next child of G (order: increasing slot ^ octant; g_order = 1: by entry distance, the ideal a sort would
+// give), pushes what is left of G, fetches the child and intersects its eight boxes. A leaf step tests the triangles (<= 2) of ONE leaf child of T.
+struct Tri8 { V3 v0, e1, e2; uint32_t id; };
+struct WideTree { std::vector<uint32_t> w; std::vector<Tri8> tris; std::vector<float> fb; uint32_t stack_need = 0, depth = 0; };
+static int g_precise = 0;     // 1: the children's float boxes instead of the 8-bit grid boxes (what a finer grid could give at best)
+static int g_order = 0;       // 0: octant order (what the kernels can afford); 1: exact near-to-far order
+static int g_leafloop = 0;    // 0: one leaf step, then back to the node loop (lanes with leaf children left sit the node steps out); 1: leaf steps until no lane has any
+struct Group { uint32_t base = 0, imask = 0, hits = 0; float tn[8]; bool fresh = true; };      // fresh: straight from its node step (g_order = 2: the nearest child first, exactly; later picks by octant)
+struct Lane8 {
+    V3 o, d, inv; float tmin, tmax, best; bool any, done; uint32_t hit, oct;
+    Group G; uint32_t T = 0, tbase = 0; uint8_t meta[8]; float ttn[8];
+    std::vector<Group> stk;
+    uint64_t node_steps = 0, tri_tests = 0, leaf_steps = 0; size_t max_stack = 0;
+    void start(V3 o_, V3 d_, float tmin_, float tmax_, bool any_) {
+        o = o_; d = d_; tmin = tmin_; tmax = tmax_; any = any_; best = tmax_; done = false; hit = kNone; stk.clear(); T = 0;
+        auto rc = [](float x) { const float k = 8.271806125530277e-25f; return 1.0f / (std::fabs(x) > k ? x : std::copysign(k, x)); };
+        inv = {rc(d.x), rc(d.y), rc(d.z)};
+        oct = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+        G = Group{}; G.base = 0; G.imask = 1; G.hits = 1; G.tn[0] = 0;      // the root: a group of one
+        node_steps = tri_tests = leaf_steps = 0; max_stack = 0;
+    }
+    bool wants_leaf() const { return !done && T != 0; }
+    bool wants_node() const { return !done && T == 0 && (G.hits != 0 || !stk.empty()); }
+    void settle() { if (!done && T == 0 && G.hits == 0 && stk.empty()) done = true; }
+    static int pick(const Group& g, uint32_t oct) {
+        int bs = -1; float bt = 0; uint32_t bp = 99;
+        for (int s = 0; s < 8; ++s) if (g.hits >> s & 1) {
+            if (g_order == 1 || (g_order == 2 && g.fresh)) { if (bs < 0 || g.tn[s] < bt) { bs = s; bt = g.tn[s]; } }
+            else { const uint32_t p = (uint32_t)s ^ oct; if (p < bp) { bp = p; bs = s; } }
+        }
+        return bs;
+    }
+    void node_step(const WideTree& W) {
+        ++node_steps;
+        if (G.hits == 0) { G = stk.back(); stk.pop_back(); }
+        const int s = pick(G, oct);
+        G.fresh = false;
+        const uint32_t n = G.base + (uint32_t)__builtin_popcount(G.imask & ((1u << s) - 1u));
+        G.hits &= ~(1u << s);
+        if (G.hits) { stk.push_back(G); max_stack = std::max(max_stack, stk.size()); }
+        const uint32_t* w = &W.w[(size_t)n * 32];
+        float p[3]; memcpy(p, w, 12);
+        const uint32_t imask = w[3] >> 24, leafmask = w[5] >> 24;
+        const float o3[3] = {o.x, o.y, o.z}, i3[3] = {inv.x, inv.y, inv.z};
+        Group ng; ng.base = w[4]; ng.imask = imask; ng.hits = 0;
+        T = 0; tbase = w[5] & 0xFFFFFFu; memcpy(meta, &w[6], 8);
+        const uint16_t* q = reinterpret_cast<const uint16_t*>(&w[8]);      // [axis][lo[8], hi[8]]
+        for (int c = 0; c < 8; ++c) {
+            if (!((imask | leafmask) >> c & 1)) continue;
+            float tn = tmin, tf = any ? tmax : best;
+            for (int a = 0; a < 3; ++a) {
+                uint32_t eb = ((w[3] >> (8 * a)) & 0xFFu) << 23; float step; memcpy(&step, &eb, 4);
+                float lo = p[a] + (float)q[16 * a + c] * step, hi = p[a] + (float)q[16 * a + 8 + c] * step;
+                if (g_precise) { lo = W.fb[(size_t)n * 48 + c * 6 + a]; hi = W.fb[(size_t)n * 48 + c * 6 + 3 + a]; }
+                const float t0 = (lo - o3[a]) * i3[a], t1 = (hi - o3[a]) * i3[a];
+                tn = std::max(tn, std::min(t0, t1)); tf = std::min(tf, std::max(t0, t1));
+            }
+            if (tn <= tf) { if (imask >> c & 1) { ng.hits |= 1u << c; ng.tn[c] = tn; } else { T |= 1u << c; ttn[c] = tn; } }
+        }
+        G = ng;
+        settle();
+    }
+    void leaf_step(const WideTree& W) {
+        ++leaf_steps;
+        int s = -1;
+        if (g_order == 1) { for (int c = 0; c < 8; ++c) if ((T >> c & 1) && (s < 0 || ttn[c] < ttn[s])) s = c; }
+        else { uint32_t bp = 99; for (int c = 0; c < 8; ++c) if (T >> c & 1) { const uint32_t pr = (uint32_t)c ^ oct; if (pr < bp) { bp = pr; s = c; } } }
+        T &= ~(1u << s);
+        const uint32_t first = tbase + (meta[s] & 31u), count = meta[s] >> 5;
+        for (uint32_t k = 0; k < count; ++k) {
+            ++tri_tests;
+            const Tri8& tr = W.tris[first + k];
+            V3 pv = cross(d, tr.e2); float det = dot(tr.e1, pv);
+            if (det == 0) continue;
+            float iv = 1.0f / det; V3 sv = o - tr.v0; float u = dot(sv, pv) * iv;
+            if (!(u >= 0 && u <= 1)) continue;
+            V3 qq = cross(sv, tr.e1); float v = dot(d, qq) * iv;
+            if (!(v >= 0 && u + v <= 1)) continue;
+            float t = dot(tr.e2, qq) * iv;
+            if (!(t > tmin && t < tmax)) continue;
+            if (getenv("NOCULL") && any) continue;
+            if (any) { hit = tr.id; done = true; return; }
+            if (t < best || (t == best && tr.id < hit)) { best = t; hit = tr.id; }
+        }
+        settle();
+    }
+};
+struct WaveCost8 { uint64_t checksum = 0, rays = 0, lane_nodes = 0, lane_tris = 0, lane_leaves = 0, wave_rays = 0, wave_nodes = 0, wave_leaves = 0, max_lane_nodes = 0, max_stack = 0; };
+static void run_wave8(const WideTree& W, std::vector<Lane8>& L, const std::vector<char>& act, WaveCost8& w) {
+    bool anyact = false;
+    for (size_t i = 0; i < L.size(); ++i) if (act[i]) anyact = true; else L[i].done = true;
+    if (!anyact) return;
+    ++w.wave_rays;
+    for (;;) {
+        for (;;) {
+            bool stepped = false;
+            for (auto& l : L) if (l.wants_node()) { l.node_step(W); stepped = true; }
+            if (!stepped) break;
+            ++w.wave_nodes;
+        }
+        bool leaf = false;
+        for (;;) {
+            bool stepped = false;
+            for (auto& l : L) if (l.wants_leaf()) { l.leaf_step(W); stepped = true; }
+            if (!stepped) break;
+            leaf = true; ++w.wave_leaves;
+            if (!g_leafloop) break;
+        }
+        if (!leaf) break;
+    }
+    uint64_t mx = 0;
+    for (size_t i = 0; i < L.size(); ++i) if (act[i]) {
+        ++w.rays; w.lane_nodes += L[i].node_steps; w.lane_tris += L[i].tri_tests; w.lane_leaves += L[i].leaf_steps; mx = std::max(mx, L[i].node_steps);
+        w.max_stack = std::max<uint64_t>(w.max_stack, L[i].max_stack);
+        w.checksum += L[i].any ? (L[i].hit == kNone ? 0u : 1u) : (L[i].hit == kNone ? 0u : L[i].hit + 1u);
+    }
+    w.max_lane_nodes += mx;
+}
+static void report8(const char* name, const WaveCost8& w) {
+    if (!w.rays) return;
+    printf("  %-10s rays %8llu  per lane-ray: nodes %6.2f leaf steps %5.2f tris %5.2f | per wave-ray: node steps %6.2f leaf steps %5.2f (slowest lane %6.2f)  deepest stack %llu  cost~ %7.1f\n", name,
+           (unsigned long long)w.rays, (double)w.lane_nodes / w.rays, (double)w.lane_leaves / w.rays, (double)w.lane_tris / w.rays, (double)w.wave_nodes / w.wave_rays,
+           (double)w.wave_leaves / w.wave_rays, (double)w.max_lane_nodes / w.wave_rays, (unsigned long long)w.max_stack,
+           (200.0 * w.wave_nodes + 170.0 * w.wave_leaves) / w.wave_rays);      // VALU + SALU per step: an 8-wide node step ~ 200, a two-triangle leaf step ~ 170
+}
+
+
+// Unified order (g_unified): leaf and inner children of a node take their turn in ONE order; a leaf child behind an inner one waits on the stack with
+// the rest of its node's hit mask (stack word = node index | hits) and the node's header is fetched again when the walk comes back to it ("resume").
+static int g_unified = 0;      // 1: one order; 2: + children whose entry distance lies behind the closest hit found meanwhile are dropped when their turn comes (needs the
+                               // entry distances: the ideal); 3: + the same, but only when a group is RESUMED from the stack (its node intersected again with the shorter ray)
+struct Lane8U {
+    V3 o, d, inv; float tmin, tmax, best; bool any, done; uint32_t hit, oct;
+    uint32_t node = 0, hits = 0; float tn[8];
+    struct E { uint32_t node, hits; float tn[8]; };
+    std::vector<E> stk;
+    uint64_t node_steps = 0, tri_tests = 0, leaf_steps = 0, resumes = 0; size_t max_stack = 0;
+    void start(V3 o_, V3 d_, float tmin_, float tmax_, bool any_) {
+        o = o_; d = d_; tmin = tmin_; tmax = tmax_; any = any_; best = tmax_; done = false; hit = kNone; stk.clear();
+        auto rc = [](float x) { const float k = 8.271806125530277e-25f; return 1.0f / (std::fabs(x) > k ? x : std::copysign(k, x)); };
+        inv = {rc(d.x), rc(d.y), rc(d.z)};
+        oct = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+        node = 0xFFFFFFFFu; hits = 1;      // pseudo group: the root
+        node_steps = tri_tests = leaf_steps = resumes = 0; max_stack = 0;
+    }
+    bool fresh = true;      // the group in hand comes straight from its node step (not from the stack)
+    int pick() const {
+        int bs = -1; float bt = 0; uint32_t bp = 99;
+        for (int s = 0; s < 8; ++s) if (hits >> s & 1) {
+            if (g_order == 1 || (g_order == 2 && fresh)) { if (bs < 0 || tn[s] < bt) { bs = s; bt = tn[s]; } }
+            else { const uint32_t p = (uint32_t)s ^ oct; if (p < bp) { bp = p; bs = s; } }
+        }
+        return bs;
+    }
+    bool next_is_inner(const WideTree& W) const { if (node == 0xFFFFFFFFu) return true; const int s = pick(); return (W.w[(size_t)node * 32 + 3] >> 24) >> s & 1; }
+    bool wants_node(const WideTree& W) const { return !done && next_is_inner(W); }
+    bool wants_leaf(const WideTree& W) const { return !done && !next_is_inner(W); }
+    void cull() { if (!any) for (int c = 0; c < 8; ++c) if ((hits >> c & 1) && tn[c] > best) hits &= ~(1u << c); }
+    void after() {
+        if (done) return;
+        if (g_unified == 2 && hits) cull();
+        while (!hits) {
+            if (stk.empty()) { done = true; return; }
+            node = stk.back().node; hits = stk.back().hits; memcpy(tn, stk.back().tn, sizeof(tn)); stk.pop_back(); ++resumes; fresh = false;
+            if (g_unified >= 2) { cull(); if (g_unified == 3 && !any) ++node_steps; }      // (3: the re-intersection costs a node step)
+        }
+    }
+    void node_step(const WideTree& W) {
+        ++node_steps;
+        const int s = pick();
+        uint32_t n;
+        if (node == 0xFFFFFFFFu) n = 0;
+        else { const uint32_t* pw = &W.w[(size_t)node * 32]; n = pw[4] + (uint32_t)__builtin_popcount((pw[3] >> 24) & ((1u << s) - 1u)); }
+        hits &= ~(1u << s); fresh = false;
+        if (hits) { E e; e.node = node; e.hits = hits; memcpy(e.tn, tn, sizeof(tn)); stk.push_back(e); max_stack = std::max(max_stack, stk.size()); }
+        const uint32_t* w = &W.w[(size_t)n * 32];
+        float p[3]; memcpy(p, w, 12);
+        const uint32_t valid = (w[3] >> 24) | (w[5] >> 24);
+        const float o3[3] = {o.x, o.y, o.z}, i3[3] = {inv.x, inv.y, inv.z};
+        const uint16_t* q = reinterpret_cast<const uint16_t*>(&w[8]);      // [axis][lo[8], hi[8]]
+        node = n; hits = 0; fresh = true;
+        for (int c = 0; c < 8; ++c) {
+            if (!(valid >> c & 1)) continue;
+            float t0n = tmin, tf = any ? tmax : best;
+            for (int a = 0; a < 3; ++a) {
+                uint32_t eb = ((w[3] >> (8 * a)) & 0xFFu) << 23; float step; memcpy(&step, &eb, 4);
+                float lo = p[a] + (float)q[16 * a + c] * step, hi = p[a] + (float)q[16 * a + 8 + c] * step;
+                if (g_precise) { lo = W.fb[(size_t)n * 48 + c * 6 + a]; hi = W.fb[(size_t)n * 48 + c * 6 + 3 + a]; }
+                const float t0 = (lo - o3[a]) * i3[a], t1 = (hi - o3[a]) * i3[a];
+                t0n = std::max(t0n, std::min(t0, t1)); tf = std::min(tf, std::max(t0, t1));
+            }
+            if (t0n <= tf) { hits |= 1u << c; tn[c] = t0n; }
+        }
+        after();
+    }
+    void leaf_step(const WideTree& W) {
+        ++leaf_steps;
+        const int s = pick();
+        hits &= ~(1u << s); fresh = false;
+        const uint32_t* w = &W.w[(size_t)node * 32];
+        const uint8_t* meta = reinterpret_cast<const uint8_t*>(&w[6]);
+        const uint32_t first = (w[5] & 0xFFFFFFu) + (meta[s] & 31u), count = meta[s] >> 5;
+        for (uint32_t k = 0; k < count; ++k) {
+            ++tri_tests;
+            const Tri8& tr = W.tris[first + k];
+            V3 pv = cross(d, tr.e2); float det = dot(tr.e1, pv);
+            if (det == 0) continue;
+            float iv = 1.0f / det; V3 sv = o - tr.v0; float u = dot(sv, pv) * iv;
+            if (!(u >= 0 && u <= 1)) continue;
+            V3 qq = cross(sv, tr.e1); float v = dot(d, qq) * iv;
+            if (!(v >= 0 && u + v <= 1)) continue;
+            float t = dot(tr.e2, qq) * iv;
+            if (!(t > tmin && t < tmax)) continue;
+            if (any) { hit = tr.id; done = true; return; }
+            if (t < best || (t == best && tr.id < hit)) { best = t; hit = tr.id; }
+        }
+        after();
+    }
+};
+static uint64_t g_resumes = 0;
+static void run_wave8u(const WideTree& W, std::vector<Lane8U>& L, const std::vector<char>& act, WaveCost8& w) {
+    bool anyact = false;
+    for (size_t i = 0; i < L.size(); ++i) if (act[i]) anyact = true; else L[i].done = true;
+    if (!anyact) return;
+    ++w.wave_rays;
+    for (;;) {
+        for (;;) {
+            bool stepped = false;
+            for (auto& l : L) if (l.wants_node(W)) { l.node_step(W); stepped = true; }
+            if (!stepped) break;
+            ++w.wave_nodes;
+        }
+        bool leaf = false;
+        for (;;) {
+            bool stepped = false;
+            for (auto& l : L) if (l.wants_leaf(W)) { l.leaf_step(W); stepped = true; }
+            if (!stepped) break;
+            leaf = true; ++w.wave_leaves;
+            if (!g_leafloop) break;
+        }
+        if (!leaf) break;
+    }
+    uint64_t mx = 0;
+    for (size_t i = 0; i < L.size(); ++i) if (act[i]) {
+        ++w.rays; w.lane_nodes += L[i].node_steps; w.lane_tris += L[i].tri_tests; w.lane_leaves += L[i].leaf_steps; mx = std::max(mx, L[i].node_steps);
+        w.max_stack = std::max<uint64_t>(w.max_stack, L[i].max_stack); g_resumes += L[i].resumes;
+        if (L[i].any) { const int k = L[i].hit != kNone; g_dbg[1][2 * k] += 1; g_dbg[1][2 * k + 1] += L[i].tri_tests; }
+        w.checksum += L[i].any ? (L[i].hit == kNone ? 0u : 1u) : (L[i].hit == kNone ? 0u : L[i].hit + 1u);
+    }
     w.max_lane_nodes += mx;
 }
 
@@ -282,6 +540,32 @@ int main(int argc, char** argv) {
     g_presence = argc > 6 ? (float)atof(argv[6]) : 1.0f;
     g_split = argc > 7 ? atoi(argv[7]) : 0;
     g_chain = argc > 8 ? atoi(argv[8]) : 0;
+    g_order = argc > 9 ? atoi(argv[9]) : 0;
+    g_leafloop = argc > 10 ? atoi(argv[10]) : 0;
+    g_unified = argc > 11 ? atoi(argv[11]) : 0;
+    g_precise = argc > 12 ? atoi(argv[12]) : 0;
+    // the 8-wide compressed tree as the product built it (csrc/frt_bvh8.hpp), decoded from its device form
+    WideTree WT;
+    {
+        uint32_t ts[8]; frt_scene_tree_stats(s, ts);
+        WT.w.resize((size_t)ts[2] * 32); WT.stack_need = ts[3]; WT.depth = ts[4];
+        std::vector<float> sl((size_t)ts[6] * 12);
+        WT.fb.resize((size_t)ts[2] * 48);
+        if (ts[2]) { frt_scene_get(s, 11, WT.w.data()); frt_scene_get(s, 12, sl.data()); frt_scene_get(s, 14, WT.fb.data()); }
+        WT.tris.resize(ts[6]);
+        for (uint32_t i = 0; i < ts[6]; ++i) { const float* q = &sl[(size_t)i * 12]; uint32_t id; memcpy(&id, &q[3], 4); WT.tris[i] = {{q[0], q[1], q[2]}, {q[4], q[5], q[6]}, {q[8], q[9], q[10]}, id}; }
+        printf("8-wide tree: %u nodes (%.2f children each), %u levels, stack need %u, %u triangle slots\n", ts[2], ts[2] ? (double)ts[5] / ts[2] : 0.0, ts[4], ts[3], ts[6]);
+    }
+    const bool wide = !WT.w.empty() && passes == 0 && !g_split && !g_chain;
+    WaveCost8 primary8, bounce18, shadow8, bounce28;
+    std::vector<Lane8> L8(64);
+    std::vector<Lane8U> L8U(64);
+    auto walk8 = [&](const std::vector<Lane>& Lq, const std::vector<char>& a, WaveCost8& w) {
+        if (!wide) return;
+        if (g_unified) { for (int i = 0; i < 64; ++i) if (a[i]) L8U[i].start(Lq[i].o, Lq[i].d, Lq[i].tmin, Lq[i].tmax, Lq[i].any); run_wave8u(WT, L8U, a, w); return; }
+        for (int i = 0; i < 64; ++i) if (a[i]) L8[i].start(Lq[i].o, Lq[i].d, Lq[i].tmin, Lq[i].tmax, Lq[i].any);
+        run_wave8(WT, L8, a, w);
+    };
     if (passes > 0) {
         printf("as built: SAH cost %.3f depth %u; ", sah_cost(T.t), st[0]);
         st[0] = frt::optimize_bvh2(T.t, T.tri_index, passes, 30u, st[0]);
@@ -307,6 +591,7 @@ int main(int argc, char** argv) {
             act[i] = 1;
         }
         run_wave(T, L, act, primary);
+        walk8(L, act, primary8);
         for (int i = 0; i < 64; ++i) {
             act[i] = L[i].hit != kNone;
             if (!act[i]) continue;
@@ -341,8 +626,10 @@ int main(int argc, char** argv) {
             act = actc;
         } else {
         run_walk(T, L, act2, shadow);
+        walk8(L, act2, shadow8);
         for (int i = 0; i < 64; ++i) if (act[i]) L[i].start(P[i] + N[i] * 0.001f, cosine_dir(N[i]), 0.001f, 100.0f, false);
         run_walk(T, L, act, bounce1);
+        walk8(L, act, bounce18);
         }
         for (int i = 0; i < 64; ++i) {
             bool a = act[i] && L[i].hit != kNone;
@@ -356,6 +643,7 @@ int main(int argc, char** argv) {
             act[i] = a;
         }
         run_walk(T, L, act, bounce2);
+        walk8(L, act, bounce28);
     }
     report("primary", primary); report("shadow", shadow); report("bounce 1", bounce1); report("shadow+b1", chained); report("bounce 2", bounce2);
     if (!g_chain) { WaveCost sum = shadow; sum.wave_nodes += bounce1.wave_nodes; sum.wave_leaves += bounce1.wave_leaves; sum.wave_tri_tests += bounce1.wave_tri_tests; sum.rays += bounce1.rays;
@@ -365,6 +653,18 @@ int main(int argc, char** argv) {
     report("incoherent", all);
     // what the rays hit does not depend on the schedule, the helpers or the tree: occluded shadow rays + sum of (hit triangle id + 1) over the bounce rays
     printf("hits checksum %llu %llu %llu\n", (unsigned long long)shadow.checksum, (unsigned long long)bounce1.checksum, (unsigned long long)bounce2.checksum);
+    if (wide) {
+        if (g_precise) printf("(float child boxes instead of the grid)\n");
+        printf("8-wide tree, %s order, %s, %s:\n", g_order == 1 ? "exact near-to-far" : (g_order == 2 ? "nearest child first, then octant" : "octant"), g_leafloop ? "leaf steps until no lane has a leaf child left" : "one leaf step per round",
+               g_unified ? "leaf and inner children in one order (resume = header fetched again)" : "a node's hit leaves first");
+        report8("primary", primary8); report8("shadow", shadow8); report8("bounce 1", bounce18); report8("bounce 2", bounce28);
+        WaveCost8 all8;
+        for (const WaveCost8* w : {&shadow8, &bounce18, &bounce28}) { all8.rays += w->rays; all8.lane_nodes += w->lane_nodes; all8.lane_tris += w->lane_tris; all8.lane_leaves += w->lane_leaves; all8.wave_rays += w->wave_rays; all8.wave_nodes += w->wave_nodes; all8.wave_leaves += w->wave_leaves; all8.max_lane_nodes += w->max_lane_nodes; all8.max_stack = std::max(all8.max_stack, w->max_stack); }
+        report8("incoherent", all8);
+        if (g_unified) printf("  resumes per incoherent lane-ray %.2f\n", (double)g_resumes / (double)(primary8.rays + all8.rays));
+        printf("hits checksum (8-wide) %llu %llu %llu\n", (unsigned long long)shadow8.checksum, (unsigned long long)bounce18.checksum, (unsigned long long)bounce28.checksum);
+    }
+    for (int m = 0; m < 2; ++m) printf("any-hit rays, %s: unoccluded %llu rays %.2f tris each; occluded %llu rays %.2f tris each\n", m ? "8-wide" : "quad", (unsigned long long)g_dbg[m][0], (double)g_dbg[m][1] / std::max<uint64_t>(g_dbg[m][0], 1), (unsigned long long)g_dbg[m][2], (double)g_dbg[m][3] / std::max<uint64_t>(g_dbg[m][2], 1));
     frt_scene_destroy(s);
     return 0;
 }
