@@ -17,6 +17,12 @@ static constexpr int kBlock = 256;
 // subtree is at most kMaxBvhDepth = 30 deep), so the LAST row of the array is never a stack entry: the workgroup's few shared words (ray-count
 // partial sums, the queue reservation scratch) live there.
 static constexpr int kMiscRow = kStackDepth - 1;
+// Kernels that walk the 8-wide tree (WALK >= kWalkWide; frt_trace.hpp: trace8) need one stack word per level: kStack8 rows + one row for the shared
+// words = 9 KiB, and — kWalkWideLds — the whole tree behind them in dynamic LDS (128 bytes per node: 27 KiB for the Cornell Box's 216 nodes).
+template <int WALK> struct WalkLds { static constexpr int kRows = kStackDepth, kMisc = kMiscRow; };
+template <> struct WalkLds<kWalkWide> { static constexpr int kRows = kStack8 + 1, kMisc = kStack8; };
+template <> struct WalkLds<kWalkWideLds> { static constexpr int kRows = kStack8 + 1, kMisc = kStack8; };
+extern __shared__ uint4 s_wide_nodes[];      // dynamic LDS of the kWalkWideLds kernels
 #ifndef FRT_WAVES
 #define FRT_WAVES 4      // waves per SIMD the traced kernels are built for (A/B builds: 5 needs <= 96 VGPRs and <= 32 KiB of LDS per workgroup)
 #endif
@@ -53,17 +59,37 @@ __device__ __forceinline__ const uint32_t* stage_top_nodes(const SceneView& sc, 
     return s_top;
 }
 
-// G-buffer: one primary ray per pixel, coherent within the 8x8 tile (lane utilisation 96 %): plain thread-per-pixel launch.
-__global__ void __launch_bounds__(kBlock) gbuffer_kernel(SceneView sc, FrameView fv) {
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
-    uint32_t* const s_cnt = &s_stack[kMiscRow * kBlock];
+// The whole 8-wide tree copied into the workgroup's dynamic LDS (kWalkWideLds): every node step of every walk then reads its node at the LDS's
+// latency and leaves the L1 to the triangles. Call before the workgroup's first barrier.
+__device__ __forceinline__ void stage_wide_nodes(const SceneView& sc) {
+    const uint32_t n = sc.num_nodes8 * 8u;      // uint4s
+    for (uint32_t i = threadIdx.x; i < n; i += (uint32_t)kBlock) s_wide_nodes[i] = sc.nodes8[i];
+}
+// VOTE: the traced kernels of scenes with a deep tree walk it with the voting loop (frt_trace.hpp: trace4<ANY, VOTE>; frt_renderer.hip: kVoteMinQuadNodes).
+// WALK: 0 the quad walk, 1 the quad walk with the voting loop, kWalkWide / kWalkWideLds the 8-wide walk.
+template <int WALK> struct CtxOf { typedef PathCtx type; };
+template <> struct CtxOf<1> { typedef VotePathCtx type; };
+template <> struct CtxOf<kWalkWide> { typedef Wide8PathCtx type; };
+template <> struct CtxOf<kWalkWideLds> { typedef Wide8PathCtx type; };
+// Workgroup prologue shared by the traced kernels: clears the shared words, stages the tree's top (quad walk) or the whole tree (kWalkWideLds) in LDS,
+// returns the context's tree pointer set up. One barrier inside.
+template <int WALK, class Ctx>
+__device__ __forceinline__ void walk_prologue(const SceneView& sc, uint32_t* s_cnt, Ctx& c) {
     if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
-    const uint32_t* const s_top = stage_top_nodes(sc, s_cnt);
+    if constexpr (WALK == kWalkWideLds) { stage_wide_nodes(sc); c.nb = reinterpret_cast<const char*>(s_wide_nodes); }
+    else if constexpr (WALK < kWalkWide) c.lds_top = stage_top_nodes(sc, s_cnt);
     __syncthreads();
+}
+
+// G-buffer: one primary ray per pixel, coherent within the 8x8 tile (lane utilisation 96 %): plain thread-per-pixel launch.
+template <int WALK>
+__global__ void __launch_bounds__(kBlock) gbuffer_kernel(SceneView sc, FrameView fv) {
+    __shared__ uint32_t s_stack[WalkLds<WALK>::kRows * kBlock];
+    uint32_t* const s_cnt = &s_stack[WalkLds<WALK>::kMisc * kBlock];
+    typename CtxOf<WALK>::type c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
+    walk_prologue<WALK>(sc, s_cnt, c);
     uint32_t px, py;
     bool active = tile_pixel(fv, px, py);
-    PathCtx c(sc, fv, &s_stack[threadIdx.x], (uint32_t)kBlock);
-    c.lds_top = s_top;
     if (active) gbuffer_pixel(c, px, py);
     bool counted = active && py >= fv.own_y0 && py < fv.own_y1;
     flush_ray_counters(fv, counted ? c.n_closest : 0u, counted ? c.n_any : 0u, s_cnt);
@@ -141,26 +167,19 @@ __device__ __forceinline__ bool run_segment_and_park(Ctx& c, LoopState& s, uint3
     return parked;
 }
 
-// VOTE: the traced kernels of scenes with a deep tree walk it with the voting loop (frt_trace.hpp: trace4<ANY, VOTE>; frt_renderer.hip: kVoteMinQuadNodes).
-template <bool VOTE> struct CtxOf { typedef PathCtx type; };
-template <> struct CtxOf<true> { typedef VotePathCtx type; };
-
-template <int STAGE, bool VOTE>
+template <int STAGE, int WALK>
 __global__ void __launch_bounds__(kBlock, FRT_WAVES) pixel_kernel(SceneView sc, FrameView fv, ContQueue q, uint32_t cut, uint32_t* zero_counts, bool wg_park) {
     constexpr int THREADS = kBlock;
-    __shared__ uint32_t s_stack[kStackDepth * THREADS];
-    uint32_t* const s_cnt = &s_stack[kMiscRow * THREADS];
+    __shared__ uint32_t s_stack[WalkLds<WALK>::kRows * THREADS];
+    uint32_t* const s_cnt = &s_stack[WalkLds<WALK>::kMisc * THREADS];
     uint32_t* const s_tmp = s_cnt + 8;
-    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
-    const uint32_t* const s_top = stage_top_nodes(sc, s_cnt);
-    __syncthreads();
+    typename CtxOf<WALK>::type c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
+    walk_prologue<WALK>(sc, s_cnt, c);
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
     // the queue counters this stage's NEXT launch will use (the other set of the pair) are cleared here instead of by a memset
     if (zero_counts && blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x <= (uint32_t)kMaxCuts) zero_counts[threadIdx.x] = 0u;
     uint32_t px, py;
     const bool active = tile_pixel(fv, px, py);      // tile rows top to bottom (a sweep from the expensive end of the image was measured: 1-2 % slower, profiles/r2_experiments)
-    typename CtxOf<VOTE>::type c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
-    c.lds_top = s_top;
     const uint32_t pix = py * fv.W + px;
     const bool counted = active && py >= fv.own_y0 && py < fv.own_y1;
     LoopState s;
@@ -198,11 +217,11 @@ __global__ void __launch_bounds__(kBlock, FRT_WAVES) pixel_kernel(SceneView sc, 
 }
 
 // Resumes parked paths for bounces [d0, d1); survivors are parked again in `qout` (d1 < MAX_DEPTH) or finished here.
-template <int STAGE, bool VOTE>
+template <int STAGE, int WALK>
 __global__ void __launch_bounds__(kBlock, FRT_WAVES) continue_kernel(SceneView sc, FrameView fv, ContQueue qin, ContQueue qout, uint32_t d0, uint32_t d1) {
     constexpr int THREADS = kBlock;
-    __shared__ uint32_t s_stack[kStackDepth * THREADS];
-    uint32_t* const s_cnt = &s_stack[kMiscRow * THREADS];
+    __shared__ uint32_t s_stack[WalkLds<WALK>::kRows * THREADS];
+    uint32_t* const s_cnt = &s_stack[WalkLds<WALK>::kMisc * THREADS];
     const uint32_t filled = *qin.count;
     const uint32_t n = filled < qin.capacity ? filled : qin.capacity;
     // The launch that parked these paths ran out of slots (its counter ran past the capacity; the surplus paths were finished in place): tell the
@@ -213,12 +232,9 @@ __global__ void __launch_bounds__(kBlock, FRT_WAVES) continue_kernel(SceneView s
         if (seen) *reinterpret_cast<volatile uint32_t*>(seen) = 1u;
     }
     if (blockIdx.x * (uint32_t)THREADS >= n) return;   // uniform per workgroup
-    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
-    const uint32_t* const s_top = stage_top_nodes(sc, s_cnt);
-    __syncthreads();
     constexpr int VARIANT = STAGE == 1 ? 0 : 1;
-    typename CtxOf<VOTE>::type c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
-    c.lds_top = s_top;
+    typename CtxOf<WALK>::type c(sc, fv, &s_stack[threadIdx.x], (uint32_t)THREADS);
+    walk_prologue<WALK>(sc, s_cnt, c);
     uint32_t cnt_closest = 0u, cnt_any = 0u;
     // stride loop: one trip with the grid of launch_trace_continuations; uniform per workgroup for any grid
     for (uint32_t base = blockIdx.x * (uint32_t)THREADS; base < n; base += gridDim.x * (uint32_t)THREADS) {
@@ -326,9 +342,10 @@ static ContQueue queue_of(const TraceLaunch& L, uint32_t k) {
 }
 static uint32_t first_cut(const TraceLaunch& L, const FrameView& fv) { return L.ncuts ? L.cuts[0] : fv.max_depth; }
 
-hipError_t launch_gbuffer(const SceneView& sc, const FrameView& fv, hipStream_t stream) {
+hipError_t launch_gbuffer(const SceneView& sc, const FrameView& fv, hipStream_t stream, uint32_t walk) {
     if (empty_rows(fv)) return hipSuccess;
-    hipLaunchKernelGGL(gbuffer_kernel, grid_for(fv), dim3(kBlock), 0, stream, sc, fv);
+    if (walk >= (uint32_t)kWalkWide) hipLaunchKernelGGL(gbuffer_kernel<kWalkWide>, grid_for(fv), dim3(kBlock), 0, stream, sc, fv);
+    else hipLaunchKernelGGL(gbuffer_kernel<kWalkQuad>, grid_for(fv), dim3(kBlock), 0, stream, sc, fv);
     return hipGetLastError();
 }
 hipError_t launch_post(const FrameView& fv, hipStream_t stream) {
@@ -357,9 +374,14 @@ hipError_t launch_trace_pixels(int stage, const SceneView& sc, const FrameView& 
 #if FRT_EXPERIMENTS
     if (L.resident) return exp_launch_resident_pixels(stage, sc, fv, stream, L);
 #endif
-    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), L.zero_counts, L.wg_park); };
-    if (stage == 1) { if (L.vote) go(pixel_kernel<1, true>); else go(pixel_kernel<1, false>); }
-    else { if (L.vote) go(pixel_kernel<2, true>); else go(pixel_kernel<2, false>); }
+    auto go = [&](auto kernel, uint32_t lds = 0u) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), L.zero_counts, L.wg_park); };
+    if (stage == 1) {
+        if (L.walk == (uint32_t)kWalkWideLds) go(pixel_kernel<1, kWalkWideLds>, L.wide_lds_bytes); else if (L.walk == (uint32_t)kWalkWide) go(pixel_kernel<1, kWalkWide>);
+        else if (L.vote) go(pixel_kernel<1, 1>); else go(pixel_kernel<1, 0>);
+    } else {
+        if (L.walk == (uint32_t)kWalkWideLds) go(pixel_kernel<2, kWalkWideLds>, L.wide_lds_bytes); else if (L.walk == (uint32_t)kWalkWide) go(pixel_kernel<2, kWalkWide>);
+        else if (L.vote) go(pixel_kernel<2, 1>); else go(pixel_kernel<2, 0>);
+    }
     return hipGetLastError();
 }
 bool trace_has_continuations(const TraceLaunch& L, uint32_t max_depth) { return L.ncuts > 0 && L.cuts[0] < max_depth; }
@@ -374,9 +396,14 @@ hipError_t launch_trace_continuations(int stage, const SceneView& sc, const Fram
         const uint32_t gslots = std::max(queue_of(L, k).capacity, L.grid_min_slots);   // (workgroups beyond the queue's fill retire at once)
         const dim3 cgrid((gslots + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
         const uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
-        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, cgrid, dim3(kBlock), 0, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1); };
-        if (stage == 1) { if (L.vote) go(continue_kernel<1, true>); else go(continue_kernel<1, false>); }
-        else { if (L.vote) go(continue_kernel<2, true>); else go(continue_kernel<2, false>); }
+        auto go = [&](auto kernel, uint32_t lds = 0u) { hipLaunchKernelGGL(kernel, cgrid, dim3(kBlock), lds, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1); };
+        if (stage == 1) {
+            if (L.walk == (uint32_t)kWalkWideLds) go(continue_kernel<1, kWalkWideLds>, L.wide_lds_bytes); else if (L.walk == (uint32_t)kWalkWide) go(continue_kernel<1, kWalkWide>);
+            else if (L.vote) go(continue_kernel<1, 1>); else go(continue_kernel<1, 0>);
+        } else {
+            if (L.walk == (uint32_t)kWalkWideLds) go(continue_kernel<2, kWalkWideLds>, L.wide_lds_bytes); else if (L.walk == (uint32_t)kWalkWide) go(continue_kernel<2, kWalkWide>);
+            else if (L.vote) go(continue_kernel<2, 1>); else go(continue_kernel<2, 0>);
+        }
     }
     return hipGetLastError();
 }

@@ -114,6 +114,7 @@ struct frt_renderer {
     uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state, or null
     bool wg_park = true;                   // pixel kernels reserve queue slots once per workgroup (FRT_WG_PARK=0: once per wave, experiment knob)
     bool vote = false;                     // traced kernels with the voting BVH walk (set from the size of the scene's quad tree, upload_scene)
+    uint32_t walk = kWalkQuad, wide_lds_bytes = 0;      // which tree the traced kernels walk (frt_kernels.hpp: kWalk*; upload_scene)
     bool wavefront = false;                // ray-level wavefront (FRT_WAVEFRONT=1): per bounce depth a trace launch and a shade launch
     uint32_t* d_wf_words[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint32_t* d_wf_items[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     uint32_t* d_wf_hits[2] = {nullptr, nullptr}; uint32_t* d_wf_counts = nullptr;   // per stage: records x 2, item lists x 2, hit buffer; 2 x 96 counters
@@ -176,6 +177,10 @@ static int upload(frt_renderer* r, const std::vector<T>& v, const D** out) {
 #define FRT_VOTE_MIN_NODES 32768      // (4 MiB of quad nodes; A/B builds: 0 = every scene votes, a huge value = none does)
 #endif
 static const size_t kVoteMinQuadNodes = FRT_VOTE_MIN_NODES;
+#ifndef FRT_WIDE_LDS_MAX
+#define FRT_WIDE_LDS_MAX 28672      // bytes of 8-wide nodes a traced workgroup may hold in LDS beside its 9 KiB of stack words: 4 workgroups per CU (A/B builds)
+#endif
+static const size_t kWideLdsMaxBytes = FRT_WIDE_LDS_MAX;
 static int upload_scene(frt_renderer* r, const SceneBuilder& b) {
     SceneView& sv = r->sv;
     int rc;
@@ -187,6 +192,21 @@ static int upload_scene(frt_renderer* r, const SceneBuilder& b) {
     // 1.279 / 1.340 ms; 390 (the Cornell Box) 1.565 / 1.611 ms.
     r->vote = b.quad_nodes.size() >= kVoteMinQuadNodes;
     if ((rc = upload(r, b.tri_slots, &sv.tris))) return rc;
+    // The 8-wide tree (frt_bvh8.hpp; frt_trace.hpp: trace8) is walked on request (FRT_FLAG_WALK_WIDE / _HBM) when the scene has one whose stack fits
+    // trace8's kStack8 words. A tree of at most kWideLdsMaxBytes is then copied into every traced workgroup's LDS (kWalkWideLds; the Cornell Box: 174
+    // nodes, 22 KiB; FRT_FLAG_WALK_WIDE_HBM leaves it in HBM). Measured slower than the quad walk on every scene (profiles/r4_experiments/wide8.md):
+    // Cornell Box 1.57 (LDS) / 1.60 (HBM) vs 1.54 ms per frame, ReSTIR scene 1.52 vs 1.27, configs[3] stand-in 3.50 vs 2.99, configs[4] stand-in 26.0 vs 19.6.
+    sv.nodes8 = nullptr; sv.tris8 = nullptr; sv.num_nodes8 = 0u; sv.stack_need8 = 0u;
+    r->walk = kWalkQuad; r->wide_lds_bytes = 0u;
+    if (b.wide8.ok && b.wide8.stack_need <= (uint32_t)kStack8 && (r->flags & (FRT_FLAG_WALK_WIDE | FRT_FLAG_WALK_WIDE_HBM))) {
+        if ((rc = upload(r, b.wide8.words, &sv.nodes8))) return rc;
+        if ((rc = upload(r, b.tri_slots8, &sv.tris8))) return rc;
+        sv.num_nodes8 = (uint32_t)(b.wide8.words.size() / kWide8Words); sv.stack_need8 = b.wide8.stack_need;
+        const size_t bytes = b.wide8.words.size() * sizeof(uint32_t);
+        r->walk = (bytes <= kWideLdsMaxBytes && !(r->flags & FRT_FLAG_WALK_WIDE_HBM)) ? kWalkWideLds : kWalkWide;
+        r->wide_lds_bytes = r->walk == kWalkWideLds ? (uint32_t)bytes : 0u;
+        r->vote = false;
+    }
     if ((rc = upload(r, b.qnode_a, &sv.qnode_a))) return rc;
     if ((rc = upload(r, b.qnode_b, &sv.qnode_b))) return rc;
     for (int a = 0; a < 3; ++a) { sv.qmin[a] = b.qmin[a]; sv.qstep[a] = b.qstep[a]; }
@@ -745,6 +765,7 @@ static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, Tr
     memset(&L, 0, sizeof(L));
     L.wg_park = r->wg_park;
     L.vote = r->vote;
+    L.walk = r->walk; L.wide_lds_bytes = r->wide_lds_bytes;
     L.refill = r->refill; L.refill_min = r->refill_min; L.stream = r->stream_mode; L.shade_min = r->shade_min; L.slice = r->stream_slice;
     L.resident = r->resident; L.res_nodes = r->res_nodes; L.res_tris = r->res_tris; L.num_cus = r->num_cus; L.res_batch = r->res_batch;
     L.work = r->d_work + ((size_t)(stage - 1) * kWorkSlots + (size_t)work_slot) * 2;
@@ -787,7 +808,7 @@ static int launch_g_and_trace(frt_renderer* r, FrameView fv, hipStream_t q, bool
         fv.ray_counters = r->d_counters + (pending ? C_PENDING + 4 * pending_set : C_STAGE);
         frt_renderer::Timed t{};
         if (timed) { int rc = timer_begin(r, t, 0, q); if (rc) return rc; }
-        HIP_TRY(launch_gbuffer(r->sv, fv, q));
+        HIP_TRY(launch_gbuffer(r->sv, fv, q, r->walk));
         if (timed) { int rc = timer_end(r, t, q); if (rc) return rc; }
         r->stats.launches[0] += 1;
     }

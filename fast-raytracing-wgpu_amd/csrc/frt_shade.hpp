@@ -83,6 +83,22 @@ struct VotePathCtx : PathCtx {
     FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) { HitRec h; n_any++; walk<true, true>(o, d, tmin, tmax, h); return h.tri != 0xFFFFFFFFu; }
 };
 
+// The context of the kernels that walk the 8-wide tree (frt_trace.hpp: trace8). `nb`: node 0 of the tree — in HBM (SceneView::nodes8), or the workgroup's
+// LDS copy of the whole tree when it is small enough (frt_kernels.hip: stage_wide_nodes). The stack column has kStack8 entries.
+struct Wide8PathCtx : PathCtx {
+    const char* nb;
+    FRT_HD Wide8PathCtx(const SceneView& s, const FrameView& f, uint32_t* st, uint32_t sd) : PathCtx(s, f, st, sd), nb(reinterpret_cast<const char*>(s.nodes8)) {}
+    template <bool ANY>
+    FRT_HD void walk8(f3 o, f3 d, float tmin, float tmax, HitRec& h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (FRT_DBG_TWICE & (ANY ? 2 : 1)) { HitRec h2; f3 o2 = o; asm volatile("" : "+v"(o2.x)); trace8<ANY>(sc, nb, o2, d, tmin, tmax, stk, stride, h2); asm volatile("" :: "v"(h2.t), "v"(h2.tri)); }
+#endif
+        trace8<ANY>(sc, nb, o, d, tmin, tmax, stk, stride, h);
+    }
+    FRT_HD void closest(f3 o, f3 d, float tmin, float tmax, HitRec& h) { n_closest++; walk8<false>(o, d, tmin, tmax, h); }
+    FRT_HD bool any(f3 o, f3 d, float tmin, float tmax) { HitRec h; n_any++; walk8<true>(o, d, tmin, tmax, h); return h.tri != 0xFFFFFFFFu; }
+};
+
 FRT_HD float rand_lcg(uint32_t& state) {   // restir.wgsl:781-786
     uint32_t old = state;
     state = old * 747796405u + 2891336453u;
@@ -344,7 +360,8 @@ FRT_HD ReservoirView zero_reservoir() { ReservoirView r; r.y = 0u; r.w_sum = 0.0
 
 // ================================================================================================ stage 0
 // gbuffer.wgsl:91-255
-FRT_HD void gbuffer_pixel(PathCtx& c, uint32_t px, uint32_t py) {
+template <class Ctx>
+FRT_HD void gbuffer_pixel(Ctx& c, uint32_t px, uint32_t py) {
     const SceneView& sc = c.sc; const FrameView& fv = c.fv;
     uint32_t pix = py * fv.W + px;
     f2 size = mk2((float)fv.W, (float)fv.H);
@@ -355,8 +372,7 @@ FRT_HD void gbuffer_pixel(PathCtx& c, uint32_t px, uint32_t py) {
     f4 target = mul(mul(view_inv, proj_inv), mk4(ndc.x, ndc.y, 1.0f, 1.0f));   // (view_inv * proj_inv) * v, :104
     f3 direction = normalize(xyz(target) / target.w - origin);
     HitRec h;
-    c.n_closest++;
-    trace4<false>(sc, origin, direction, 0.001f, 1000.0f, c.stk, c.stride, h, c.lds_top);
+    c.closest(origin, direction, 0.001f, 1000.0f, h);
     if (h.tri == 0xFFFFFFFFu) {
         fv.gpos[pix] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
         fv.gnormal[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -374,7 +374,8 @@ FRT_HD void trace8(const SceneView& sc, const char* nb, f3 o, f3 d, float tmin, 
     hit.t = tmax; hit.tri = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f; hit.inst = 0u; hit.front = false;
     float best_det = 0.0f;
     const f3 inv = mk3(prune_rcp(d.x), prune_rcp(d.y), prune_rcp(d.z));
-    const uint32_t nxo = 32u | ((f2u(d.x) >> 31) << 4), nyo = 64u | ((f2u(d.y) >> 31) << 4), nzo = 96u | ((f2u(d.z) >> 31) << 4);      // near plane blocks; far = ^ 16
+    const uint32_t nxo = 32u | ((f2u(d.x) >> 31) << 4), nyo = 64u | ((f2u(d.y) >> 31) << 4), nzo = 96u | ((f2u(d.z) >> 31) << 4);      // near plane blocks
+    const uint32_t fxo = nxo ^ 16u, fyo = nyo ^ 16u, fzo = nzo ^ 16u;                                                                         // far plane blocks
     const uint32_t oct = (f2u(d.x) >> 31) | ((f2u(d.y) >> 31) << 1) | ((f2u(d.z) >> 31) << 2);
     const uint32_t om = (0x55u << (oct & 1u)) | ((0x33u << (oct & 2u)) << 8) | ((0x0Fu << (oct & 4u)) << 16);
     const uint32_t kNone = 0xFFFFFFFFu;
@@ -394,13 +395,13 @@ FRT_HD void trace8(const SceneView& sc, const char* nb, f3 o, f3 d, float tmin, 
         while (T == 0u && cur != kNone) {
             const uint32_t noff = cur << 7;
             const uint4 h0 = *reinterpret_cast<const uint4*>(nb + noff), h1 = *reinterpret_cast<const uint4*>(nb + (noff + 16u));
-            const uint4 qnx = *reinterpret_cast<const uint4*>(nb + (noff | nxo)), qfx = *reinterpret_cast<const uint4*>(nb + (noff | (nxo ^ 16u)));
-            const uint4 qny = *reinterpret_cast<const uint4*>(nb + (noff | nyo)), qfy = *reinterpret_cast<const uint4*>(nb + (noff | (nyo ^ 16u)));
-            const uint4 qnz = *reinterpret_cast<const uint4*>(nb + (noff | nzo)), qfz = *reinterpret_cast<const uint4*>(nb + (noff | (nzo ^ 16u)));
+            const uint4 qnx = *reinterpret_cast<const uint4*>(nb + (noff | nxo)), qfx = *reinterpret_cast<const uint4*>(nb + (noff | fxo));
+            const uint4 qny = *reinterpret_cast<const uint4*>(nb + (noff | nyo)), qfy = *reinterpret_cast<const uint4*>(nb + (noff | fyo));
+            const uint4 qnz = *reinterpret_cast<const uint4*>(nb + (noff | nzo)), qfz = *reinterpret_cast<const uint4*>(nb + (noff | fzo));
             const float sx = u2f((h0.w & 0xFFu) << 23) * inv.x, sy = u2f(((h0.w >> 8) & 0xFFu) << 23) * inv.y, sz = u2f(((h0.w >> 16) & 0xFFu) << 23) * inv.z;
             const float bx = (u2f(h0.x) - o.x) * inv.x, by = (u2f(h0.y) - o.y) * inv.y, bz = (u2f(h0.z) - o.z) * inv.z;
             const float tlim = ANY ? tmax : hit.t;
-            const uint32_t imask = h0.w >> 24, leafmask = h1.y >> 24;
+            const uint32_t imask = h0.w >> 24;
             const uint32_t wnx[4] = {qnx.x, qnx.y, qnx.z, qnx.w}, wfx[4] = {qfx.x, qfx.y, qfx.z, qfx.w};
             const uint32_t wny[4] = {qny.x, qny.y, qny.z, qny.w}, wfy[4] = {qfy.x, qfy.y, qfy.z, qfy.w};
             const uint32_t wnz[4] = {qnz.x, qnz.y, qnz.z, qnz.w}, wfz[4] = {qfz.x, qfz.y, qfz.z, qfz.w};
@@ -422,13 +423,19 @@ FRT_HD void trace8(const SceneView& sc, const char* nb, f3 o, f3 d, float tmin, 
                 }
             }
             const uint32_t ih = hits & imask;
-            T = hits & leafmask;
-            if (T) { T |= h1.y << 8; meta0 = h1.z; meta1 = h1.w; }
+            // (the header's second half is used under conditions only: left alone, the compiler sinks the load of child_base into the branch below —
+            // a second dependent round trip in every node step. Pinning the words here keeps all eight loads of a step in flight together.)
+            uint32_t child_base = h1.x, tri_word = h1.y, m0 = h1.z, m1 = h1.w;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(child_base), "+v"(tri_word), "+v"(m0), "+v"(m1));
+#endif
+            T = hits & (tri_word >> 24);
+            if (T) { T |= tri_word << 8; meta0 = m0; meta1 = m1; }
             if (ih) {
                 const uint32_t s = ANY ? (kmin & 7u) : pick_octant(ih, om);
-                cur = h1.x + popc32(imask & ((1u << s) - 1u));
+                cur = child_base + popc32(imask & ((1u << s) - 1u));
                 const uint32_t rem = ih & ~(1u << s);
-                if (rem) { *top = (h1.x << 16) | (imask << 8) | rem; top += stride; }
+                if (rem) { *top = (child_base << 16) | (imask << 8) | rem; top += stride; }
             } else if (T) cur = kNone;      // (the stack is looked at after this node's leaves)
             else from_stack();
         }

@@ -13,7 +13,7 @@ orc = Oracle(os.path.join(ROOT, "oracle", "_build", "liborc.so"))
 
 def run(name, scene, W, H, depth, nlights, frames=40, warm=8):
     cams = [frt.CameraController().build_uniform(W / H, f, nlights) for f in range(frames)]
-    r = frt.Renderer(scene, W, H, max_depth=depth, flags=frt.FLAG_TIMING | frt.FLAG_OVERLAP_POST)
+    r = frt.Renderer(scene, W, H, max_depth=depth, flags=frt.FLAG_TIMING | frt.FLAG_OVERLAP_POST | int(os.environ.get("FRT_EXTRA_FLAGS", "0")))      # e.g. 32 = FLAG_WALK_WIDE
     for f in range(warm): r.render(cams[f])
     r.sync(); s0 = r.stats(); t0 = time.perf_counter()
     for f in range(warm, frames): r.render(cams[f])
@@ -22,7 +22,7 @@ def run(name, scene, W, H, depth, nlights, frames=40, warm=8):
     rays = s1["rays_closest"] + s1["rays_any"] - s0["rays_closest"] - s0["rays_any"]
     ms = [(a - b) / n for a, b in zip(s1["ms_stage"], s0["ms_stage"])]
     c = scene.counts()
-    out = {"workload": name, "triangles": c["tris"], "lights": c["lights"], "width": W, "height": H, "max_depth": depth,
+    out = {"extra_flags": int(os.environ.get("FRT_EXTRA_FLAGS", "0")), "workload": name, "triangles": c["tris"], "lights": c["lights"], "width": W, "height": H, "max_depth": depth,
            "ms_per_frame": (t1 - t0) / n * 1e3, "Mrays_per_s": rays / (t1 - t0) / 1e6, "Mrays_per_frame": rays / n / 1e6,
            "stage_ms": dict(zip(("gbuffer", "temporal", "spatial", "post"), ms))}
     print(json.dumps(out), flush=True)
