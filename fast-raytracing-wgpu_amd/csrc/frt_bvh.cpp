@@ -14,6 +14,8 @@
 #include <cstring>
 #include <limits>
 #include <cstdlib>
+#include <cstdio>
+#include <memory>
 
 namespace frt {
 
@@ -117,7 +119,10 @@ struct Builder {
 };
 } // namespace
 
-static const size_t kBvhOptMinTris = 8192;
+#ifndef FRT_BVH_OPT_MIN
+#define FRT_BVH_OPT_MIN 8192      // (A/B builds: 0 = every scene goes through the insertion pass)
+#endif
+static const size_t kBvhOptMinTris = FRT_BVH_OPT_MIN;
 
 void SceneBuilder::build_bvh2() {
     bvh2.clear(); bvh2_tri_index.clear();
@@ -198,7 +203,16 @@ static void quantize_pair_nodes(SceneBuilder& b) {
 // Traversal stack: a node with k children hit pushes k - 1 references, so a folded tree can need more entries than the binary one. A fold is
 // therefore only made while every inner child could still be finished as a plain binary subtree within kStackDepth entries (`used` = what the
 // ancestors may already have pushed): the quad tree of any scene the builder accepts (depth <= kMaxBvhDepth) fits the stack by construction.
-static void build_quad_nodes(SceneBuilder& b) {
+// Which binary nodes fold into one quad node: the surface-area dynamic programme of frt_bvh8.hpp (WideCollapse, 4 slots) when `dp`, else the greedy fold
+// described above. The programme fills the nodes better (Cornell Box: 3.5 instead of 3.0 children per node, 331 instead of 390 nodes) but knows nothing of the
+// traversal stack: a tree it makes too deep for the stack (the 82k- and 246k-triangle stand-ins: 36 and 39 entries) is built again with the greedy fold,
+// which stays inside the budget by construction. Measured (profiles/r4_experiments/quad_dp.md): Cornell Box 1.540 -> 1.435 ms per frame (3840x2160: 5.89 ->
+// 5.46), ReSTIR scene 1.269 -> 1.260; the mixed form — the programme only at the nodes where the greedy fold's worst-case bound (`fits`) lets it — gives
+// the deep scenes MORE nodes than the greedy fold (colonnade 81,964 vs 71,172: 20.9 vs 19.7 ms) and is not used.
+#ifndef FRT_QUAD_DP
+#define FRT_QUAD_DP 1
+#endif
+static void build_quad_nodes(SceneBuilder& b, int dp = FRT_QUAD_DP ? 2 : 0) {      // 2: the programme everywhere; 0: the greedy fold (1: the programme where the stack bound below lets it, the greedy fold elsewhere: measured, not used)
     b.quad_nodes.clear(); b.quad_stack_need = 0;
     const std::vector<frt_bvh2_node>& t = b.bvh2;
     const uint32_t budget = (uint32_t)kStackDepth - 1u;
@@ -211,12 +225,16 @@ static void build_quad_nodes(SceneBuilder& b) {
     };
     struct Kids { uint32_t c[4]; int n; };
     auto fits = [&](const uint32_t* c, int n, uint32_t used) {
+        if (used + (uint32_t)(n - 1) > budget) return false;      // (children that are all leaves; implied for a set the greedy fold reaches step by step)
         for (int i = 0; i < n; ++i)
             if (t[c[i]].count == 0 && used + (uint32_t)(n - 1) + (height[c[i]] - 1u) > budget) return false;
         return true;
     };
+    std::unique_ptr<WideCollapse> collapse;
+    if (dp) collapse.reset(new WideCollapse(t, 4));
     auto children_of = [&](uint32_t ni, uint32_t used) -> Kids {
         Kids k{};
+        if (dp) { k.n = collapse->children_of(ni, k.c); if (dp == 2 || fits(k.c, k.n, used)) return k; k = Kids{}; }
         if (t[ni].count > 0) { k.c[0] = ni; k.n = 1; return k; }       // a lone leaf root
         k.n = 2; k.c[0] = t[ni].left_first; k.c[1] = t[ni].left_first + 1;
         while (k.n < 4) {
@@ -262,6 +280,9 @@ static void build_quad_nodes(SceneBuilder& b) {
         b.quad_nodes[h] = q;
     }
     b.quad_stack_need = need[0];
+    b.quad_fold = (uint32_t)dp;
+    if (getenv("FRT_DEBUG_FOLD")) fprintf(stderr, "quad fold mode %d: %zu nodes, stack need %u (budget %u)\n", dp, order.size(), b.quad_stack_need, budget);
+    if (dp && b.quad_stack_need > budget) { build_quad_nodes(b, 0); return; }
     if (b.quad_stack_need > (uint32_t)kStackDepth - 1u) b.error = "quad tree exceeds the traversal stack";   // (cannot happen: see above; the last row of the LDS array is not a stack entry, frt_kernels.hip: kMiscRow)
 }
 

@@ -82,6 +82,65 @@ inline void assign_min(const double a[8][8], int n, int col_of_row[8]) {
 }
 }   // namespace wide8_detail
 
+// Which nodes of the binary tree become wide nodes of `width` (4 or 8) slots: the dynamic programme of Ylitie et al. (section 3.1). C(n, i) = the least
+// surface-area cost of representing the subtree under n by at most i roots (wide nodes or leaves) —
+//     C(n, 1) = area(n) + min over the ways of dealing `width` slots to n's two children of C(l, k) + C(r, width - k)      (n becomes a wide node)
+//     C(n, i) = min(C(n, i - 1), min over 0 < k < i of C(l, k) + C(r, i - k))                                               (n dissolves into its parent)
+// with a leaf of the binary tree costing 0.3 x its own area x triangles at every i. Minimising the summed area of the wide nodes is what fills them: the
+// greedy fold (open the largest child first) leaves 4.7 of 8 slots used on the Cornell Box, this 5.6; of the quad tree's 4 slots 3.0 / 3.5.
+struct WideCollapse {
+    const std::vector<frt_bvh2_node>& t;
+    int width;
+    std::vector<float> C;             // C[n * width + i], i = 1 .. width - 1 roots (index 0 unused)
+    std::vector<uint8_t> split;       // split[n * (width + 1) + i]: slots given to the left child when n's subtree gets i (i = 2 .. width; width = n is a wide node; 0 = n stays a root)
+    static float half_area(const frt_bvh2_node& n) {
+        const float dx = n.bmax[0] - n.bmin[0], dy = n.bmax[1] - n.bmin[1], dz = n.bmax[2] - n.bmin[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    WideCollapse(const std::vector<frt_bvh2_node>& tree, int w) : t(tree), width(w), C(tree.size() * (size_t)w, 0.0f), split(tree.size() * (size_t)(w + 1), 0) {
+        const size_t W = (size_t)width;
+        for (size_t n = t.size(); n-- > 0;) {                     // children follow their parent: bottom-up
+            const float area = half_area(t[n]);
+            if (t[n].count > 0) { for (size_t i = 1; i < W; ++i) C[n * W + i] = area * (float)t[n].count * 0.3f; continue; }
+            const size_t l = t[n].left_first, r = l + 1;
+            auto deal = [&](int i, uint8_t& k_best) {             // best way to give i >= 2 slots to the two children
+                float best = 3.0e38f; k_best = 1;
+                for (int k = 1; k < i; ++k) {
+                    const float c = C[l * W + (size_t)std::min(k, width - 1)] + C[r * W + (size_t)std::min(i - k, width - 1)];
+                    if (c < best) { best = c; k_best = (uint8_t)k; }
+                }
+                return best;
+            };
+            uint8_t kw; const float wide = area + deal(width, kw);
+            split[n * (W + 1) + W] = kw;
+            C[n * W + 1] = wide;
+            for (int i = 2; i < width; ++i) {
+                uint8_t k; const float d = deal(i, k);
+                if (d < C[n * W + (size_t)i - 1]) { C[n * W + (size_t)i] = d; split[n * (W + 1) + (size_t)i] = k; }
+                else { C[n * W + (size_t)i] = C[n * W + (size_t)i - 1]; split[n * (W + 1) + (size_t)i] = split[n * (W + 1) + (size_t)i - 1]; }      // (fewer roots were cheaper: the decision of i - 1)
+            }
+        }
+    }
+    // the children of wide node ni, in the binary tree's left-to-right order; returns their number (<= width)
+    int children_of(uint32_t ni, uint32_t* out) const {
+        if (t[ni].count > 0) { out[0] = ni; return 1; }       // a lone leaf root
+        const size_t W = (size_t)width;
+        struct Item { uint32_t n; int i; };
+        Item stack[32]; int sp = 0, n_out = 0;
+        const uint32_t l0 = t[ni].left_first; const int k0 = split[(size_t)ni * (W + 1) + W];
+        stack[sp++] = Item{l0 + 1, width - k0}; stack[sp++] = Item{l0, k0};
+        while (sp > 0) {
+            const Item it = stack[--sp];
+            const int i = std::min(it.i, width - 1);
+            const int ks = t[it.n].count > 0 ? 0 : split[(size_t)it.n * (W + 1) + (size_t)i];
+            if (t[it.n].count > 0 || i == 1 || ks == 0) { out[n_out++] = it.n; continue; }      // a leaf, or a wide node of its own
+            const uint32_t l = t[it.n].left_first;
+            stack[sp++] = Item{l + 1, i - ks}; stack[sp++] = Item{l, ks};
+        }
+        return n_out;
+    }
+};
+
 // t: canonical BVH2 (children adjacent, behind their parent; boxes padded). Leaves of t index triangle slots [left_first, left_first + count).
 inline void build_wide8(const std::vector<frt_bvh2_node>& t, Wide8& out) {
     out = Wide8{};
@@ -91,53 +150,11 @@ inline void build_wide8(const std::vector<frt_bvh2_node>& t, Wide8& out) {
         return dx * dy + dy * dz + dz * dx;
     };
     struct Kids { uint32_t c[8]; int n; int slot[8]; };
-    // 1. collapse. Which nodes of the binary tree become wide nodes is decided by the dynamic programme of Ylitie et al. (section 3.1): C(n, i) = the least
-    //    surface-area cost of representing the subtree under n by at most i roots (wide nodes or leaves) —
-    //        C(n, 1) = area(n) + min over the ways of dealing 8 slots to n's two children of C(l, k) + C(r, 8 - k)       (n becomes a wide node)
-    //        C(n, i) = min(C(n, i - 1), min over 0 < k < i of C(l, k) + C(r, i - k))                                      (n dissolves into its parent)
-    //    with a leaf of the binary tree costing its own area x triangles at every i. Minimising the summed area of the wide nodes is what fills them: the
-    //    greedy fold (open the largest child first; the quad tree's rule) left 4.7 of 8 slots used on the Cornell Box, this leaves FRT_WIDE8_GREEDY unset.
-    const size_t NB = t.size();
-    std::vector<float> C(NB * 8, 0.0f);                 // C[n * 8 + i], i = 1 .. 7 roots (index 0 unused); for i = 1 the wide-node cost
-    std::vector<uint8_t> split(NB * 9, 0);              // split[n * 9 + i]: slots given to the left child when n's subtree gets i (i = 2 .. 8; 8 = n is a wide node)
-    for (size_t n = NB; n-- > 0;) {                     // children follow their parent: bottom-up
-        const float area = half_area((uint32_t)n);
-        if (t[n].count > 0) { for (int i = 1; i < 8; ++i) C[n * 8 + i] = area * (float)t[n].count * 0.3f; continue; }
-        const size_t l = t[n].left_first, r = l + 1;
-        auto deal = [&](int i, uint8_t& k_best) {       // best way to give i >= 2 slots to the two children
-            float best = 3.0e38f; k_best = 1;
-            for (int k = 1; k < i; ++k) {
-                const float c = C[l * 8 + std::min(k, 7)] + C[r * 8 + std::min(i - k, 7)];
-                if (c < best) { best = c; k_best = (uint8_t)k; }
-            }
-            return best;
-        };
-        uint8_t k8; const float wide = area + deal(8, k8);
-        split[n * 9 + 8] = k8;
-        C[n * 8 + 1] = wide;
-        for (int i = 2; i < 8; ++i) {
-            uint8_t k; const float d = deal(i, k);
-            if (d < C[n * 8 + i - 1]) { C[n * 8 + i] = d; split[n * 9 + i] = k; }
-            else { C[n * 8 + i] = C[n * 8 + i - 1]; split[n * 9 + i] = split[n * 9 + i - 1]; }      // (fewer roots were cheaper: same decision as for i - 1; 0 = a wide node)
-        }
-        split[n * 9 + 1] = 0;
-    }
-    // the children of wide node ni: walk the decisions down from (ni, 8 slots)
+    // 1. collapse: WideCollapse above
+    WideCollapse dp(t, 8);
     auto children_of = [&](uint32_t ni) -> Kids {
         Kids k{};
-        if (t[ni].count > 0) { k.c[0] = ni; k.n = 1; return k; }       // a lone leaf root
-        struct Item { uint32_t n; int i; };
-        Item stack[16]; int sp = 0;
-        const uint32_t l0 = t[ni].left_first; const int k0 = split[(size_t)ni * 9 + 8];
-        stack[sp++] = Item{l0 + 1, 8 - k0}; stack[sp++] = Item{l0, k0};
-        while (sp > 0) {
-            const Item it = stack[--sp];
-            const int i = std::min(it.i, 7);
-            const int ks = t[it.n].count > 0 ? 0 : split[(size_t)it.n * 9 + i];
-            if (t[it.n].count > 0 || i == 1 || ks == 0) { k.c[k.n++] = it.n; continue; }      // a leaf, or a wide node of its own
-            const uint32_t l = t[it.n].left_first;
-            stack[sp++] = Item{l + 1, i - ks}; stack[sp++] = Item{l, ks};
-        }
+        k.n = dp.children_of(ni, k.c);
         return k;
     };
     // 2. slots: maximise sum(dot(centroid_c - centre, dir(slot))), dir(s).a = +1 where bit a of s is set, else -1

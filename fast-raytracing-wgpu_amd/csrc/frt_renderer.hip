@@ -476,7 +476,7 @@ int frt_scene_tree_stats(const frt_scene* s, uint32_t st[8]) {
     const SceneBuilder& b = s->b;
     st[0] = (uint32_t)b.quad_nodes.size(); st[1] = b.quad_stack_need;
     st[2] = b.wide8.ok ? (uint32_t)(b.wide8.words.size() / kWide8Words) : 0u; st[3] = b.wide8.stack_need; st[4] = b.wide8.depth; st[5] = b.wide8.children;
-    st[6] = (uint32_t)b.tri_slots8.size(); st[7] = 0u;
+    st[6] = (uint32_t)b.tri_slots8.size(); st[7] = b.quad_fold;
     return FRT_OK;
 }
 void frt_camera_default(float aspect, uint32_t frame_count, uint32_t num_lights, frt_camera_uniform* out) {

@@ -111,6 +111,7 @@ public:
     std::vector<PairNode> pair_nodes;
     std::vector<QuadNode> quad_nodes;       // the same tree with every other level folded away (build_quad_nodes)
     uint32_t quad_stack_need = 0;           // deepest traversal stack a ray can need in the quad tree
+    uint32_t quad_fold = 0;                 // how the quad tree was folded (frt_bvh.cpp: build_quad_nodes): 2 surface-area programme, 1 programme + greedy where the stack bound asks, 0 greedy
     std::vector<uint32_t> qnode_a, qnode_b;     // quantized pair nodes, 4 words per node each (frt_trace.hpp: QBvh)
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     std::vector<TriSlot> tri_slots;

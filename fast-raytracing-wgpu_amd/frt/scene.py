@@ -97,7 +97,7 @@ class SceneBuilder:
     def tree_stats(self):
         s = (C.c_uint32 * 8)()
         check(lib().frt_scene_tree_stats(self._h, s))
-        return dict(zip(("quad_nodes", "quad_stack_need", "wide8_nodes", "wide8_stack_need", "wide8_depth", "wide8_children", "wide8_tri_slots"), list(s)))
+        return dict(zip(("quad_nodes", "quad_stack_need", "wide8_nodes", "wide8_stack_need", "wide8_depth", "wide8_children", "wide8_tri_slots", "quad_fold"), list(s)))
 
     def get(self, what):
         n = self.counts()

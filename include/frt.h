@@ -141,7 +141,8 @@ int frt_scene_counts(const frt_scene* s, uint32_t counts[8]);
  * 14 the float boxes behind the 8-wide nodes' grid boxes (192 B per node: 8 x lo.xyz, hi.xyz; host data for tools/bvh_quality.cpp) */
 int frt_scene_get(const frt_scene* s, int which, void* out);
 /* stats[8]: quad nodes, deepest traversal stack of the quad tree, 8-wide nodes (0: the scene has no 8-wide tree: more than 65,536 nodes), deepest stack of
- * the 8-wide tree, its levels, sum of its nodes' child counts, its triangle slots, 0 */
+ * the 8-wide tree, its levels, sum of its nodes' child counts, its triangle slots, how the quad tree was folded (2 surface-area programme, 1 programme where
+ * the traversal-stack bound allows and the greedy fold elsewhere, 0 greedy fold) */
 int frt_scene_tree_stats(const frt_scene* s, uint32_t stats[8]);
 /* bvh stats[4]: max depth, leaves, max leaf size, wide-node count */
 int frt_scene_bvh_stats(const frt_scene* s, uint32_t stats[4]);

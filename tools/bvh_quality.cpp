@@ -571,7 +571,19 @@ int main(int argc, char** argv) {
         st[0] = frt::optimize_bvh2(T.t, T.tri_index, passes, 30u, st[0]);
         printf("after %d insertion passes: SAH cost %.3f depth %u\n", passes, sah_cost(T.t), st[0]);
     }
-    build_quads(T);
+    if (passes > 0) build_quads(T);      // (the tree was changed here: fold it here, greedily)
+    else {                               // the quad nodes as the product built them (frt_scene_get 10)
+        uint32_t ts[8]; frt_scene_tree_stats(s, ts);
+        std::vector<float> qn((size_t)ts[0] * 32);
+        frt_scene_get(s, 10, qn.data());
+        T.quads.resize(ts[0]); T.stack_need = ts[1];
+        for (uint32_t i = 0; i < ts[0]; ++i) {
+            Quad q{}; const float* f = &qn[(size_t)i * 32];
+            for (int a = 0; a < 3; ++a) for (int c = 0; c < 4; ++c) { q.lo[a][c] = f[8 * a + c]; q.hi[a][c] = f[8 * a + 4 + c]; }
+            for (int c = 0; c < 4; ++c) { memcpy(&q.ref[c], &f[24 + c], 4); if (q.ref[c] != kNone) q.n = c + 1; }
+            T.quads[i] = q;
+        }
+    }
     printf("%s: %u triangles, BVH2 %zu nodes depth %u, %zu quad nodes, stack need %u, SAH cost %.3f\n", which.c_str(), cnt[0], T.t.size(), st[0], T.quads.size(), T.stack_need, sah_cost(T.t));
 
     // benchmark camera: (0, 0, 3) looking down -z, 45 degrees vertical, 16:9 (camera.rs:40-42, :218-222)
