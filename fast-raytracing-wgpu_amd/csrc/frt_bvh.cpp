@@ -231,14 +231,7 @@ static void build_quad_nodes(SceneBuilder& b, int dp = FRT_QUAD_DP ? 2 : 0) {   
         return true;
     };
     std::unique_ptr<WideCollapse> collapse;
-#ifndef FRT_QUAD_LEAF_MAX
-#define FRT_QUAD_LEAF_MAX 2      // (A/B builds) the programme may turn a subtree of at most this many triangles into one leaf
-#endif
-#ifndef FRT_QUAD_CPRIM
-#define FRT_QUAD_CPRIM 0.3f
-#endif
-    if (dp) collapse.reset(new WideCollapse(t, 4, FRT_QUAD_LEAF_MAX, FRT_QUAD_CPRIM));
-    auto is_leaf = [&](uint32_t n) { return t[n].count > 0 || (dp && collapse->merged[n]); };
+    if (dp) collapse.reset(new WideCollapse(t, 4));
     auto children_of = [&](uint32_t ni, uint32_t used) -> Kids {
         Kids k{};
         if (dp) { k.n = collapse->children_of(ni, k.c); if (dp == 2 || fits(k.c, k.n, used)) return k; k = Kids{}; }
@@ -264,7 +257,7 @@ static void build_quad_nodes(SceneBuilder& b, int dp = FRT_QUAD_DP ? 2 : 0) {   
         const Kids k = children_of(order[h], used[h]);
         kids.push_back(k);
         for (int i = 0; i < k.n; ++i)
-            if (!is_leaf(k.c[i])) { quad_of[k.c[i]] = (uint32_t)order.size(); order.push_back(k.c[i]); used.push_back(used[h] + (uint32_t)(k.n - 1)); }
+            if (t[k.c[i]].count == 0) { quad_of[k.c[i]] = (uint32_t)order.size(); order.push_back(k.c[i]); used.push_back(used[h] + (uint32_t)(k.n - 1)); }
     }
     b.quad_nodes.resize(order.size());
     std::vector<uint32_t> need(order.size(), 0u);
@@ -279,7 +272,6 @@ static void build_quad_nodes(SceneBuilder& b, int dp = FRT_QUAD_DP ? 2 : 0) {   
                 const frt_bvh2_node& c = t[k.c[i]];
                 for (int a = 0; a < 3; ++a) { q.q[8 * a + i] = c.bmin[a]; q.q[8 * a + 4 + i] = c.bmax[a]; }
                 if (c.count > 0) ref = kLeafFlag | (c.count << 24) | c.left_first;
-                else if (is_leaf(k.c[i])) ref = kLeafFlag | (collapse->tri_count[k.c[i]] << 24) | collapse->tri_first[k.c[i]];
                 else { ref = quad_of[k.c[i]]; deepest = std::max(deepest, need[ref]); }
             }
             memcpy(&q.q[24 + i], &ref, 4);

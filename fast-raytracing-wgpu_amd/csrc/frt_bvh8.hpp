@@ -91,22 +91,18 @@ inline void assign_min(const double a[8][8], int n, int col_of_row[8]) {
 struct WideCollapse {
     const std::vector<frt_bvh2_node>& t;
     int width;
-    std::vector<uint32_t> tri_first, tri_count;      // the triangle slots under every binary node (contiguous: the slots are in the tree's depth-first order)
-    std::vector<uint8_t> merged;                     // an inner binary node that is cheaper as ONE leaf of its <= leaf_max triangles (leaf_max > 2 only)
     std::vector<float> C;             // C[n * width + i], i = 1 .. width - 1 roots (index 0 unused)
     std::vector<uint8_t> split;       // split[n * (width + 1) + i]: slots given to the left child when n's subtree gets i (i = 2 .. width; width = n is a wide node; 0 = n stays a root)
     static float half_area(const frt_bvh2_node& n) {
         const float dx = n.bmax[0] - n.bmin[0], dy = n.bmax[1] - n.bmin[1], dz = n.bmax[2] - n.bmin[2];
         return dx * dy + dy * dz + dz * dx;
     }
-    WideCollapse(const std::vector<frt_bvh2_node>& tree, int w, uint32_t leaf_max = 2, float c_prim = 0.3f)
-        : t(tree), width(w), tri_first(tree.size(), 0), tri_count(tree.size(), 0), merged(tree.size(), 0), C(tree.size() * (size_t)w, 0.0f), split(tree.size() * (size_t)(w + 1), 0) {
+    WideCollapse(const std::vector<frt_bvh2_node>& tree, int w) : t(tree), width(w), C(tree.size() * (size_t)w, 0.0f), split(tree.size() * (size_t)(w + 1), 0) {
         const size_t W = (size_t)width;
         for (size_t n = t.size(); n-- > 0;) {                     // children follow their parent: bottom-up
             const float area = half_area(t[n]);
-            if (t[n].count > 0) { tri_first[n] = t[n].left_first; tri_count[n] = t[n].count; for (size_t i = 1; i < W; ++i) C[n * W + i] = area * (float)t[n].count * c_prim; continue; }
+            if (t[n].count > 0) { for (size_t i = 1; i < W; ++i) C[n * W + i] = area * (float)t[n].count * 0.3f; continue; }
             const size_t l = t[n].left_first, r = l + 1;
-            tri_first[n] = std::min(tri_first[l], tri_first[r]); tri_count[n] = tri_count[l] + tri_count[r];
             auto deal = [&](int i, uint8_t& k_best) {             // best way to give i >= 2 slots to the two children
                 float best = 3.0e38f; k_best = 1;
                 for (int k = 1; k < i; ++k) {
@@ -123,16 +119,10 @@ struct WideCollapse {
                 if (d < C[n * W + (size_t)i - 1]) { C[n * W + (size_t)i] = d; split[n * (W + 1) + (size_t)i] = k; }
                 else { C[n * W + (size_t)i] = C[n * W + (size_t)i - 1]; split[n * (W + 1) + (size_t)i] = split[n * (W + 1) + (size_t)i - 1]; }      // (fewer roots were cheaper: the decision of i - 1)
             }
-            // one leaf of all the subtree's triangles, where that is cheaper than any tree over them
-            if (tri_count[n] <= leaf_max && tri_first[l] + tri_count[l] == tri_first[r]) {
-                const float leaf = area * (float)tri_count[n] * c_prim;
-                for (size_t i = 1; i < W; ++i) if (leaf < C[n * W + i]) { C[n * W + i] = leaf; split[n * (W + 1) + i] = 255; }      // 255: one leaf when the subtree gets i slots
-            }
         }
     }
-    bool is_leaf(uint32_t n) const { return t[n].count > 0 || merged[n]; }      // (merged[] is filled in by children_of: which subtrees became ONE leaf depends on the slots they were dealt)
     // the children of wide node ni, in the binary tree's left-to-right order; returns their number (<= width)
-    int children_of(uint32_t ni, uint32_t* out) {
+    int children_of(uint32_t ni, uint32_t* out) const {
         if (t[ni].count > 0) { out[0] = ni; return 1; }       // a lone leaf root
         const size_t W = (size_t)width;
         struct Item { uint32_t n; int i; };
@@ -143,8 +133,7 @@ struct WideCollapse {
             const Item it = stack[--sp];
             const int i = std::min(it.i, width - 1);
             const int ks = t[it.n].count > 0 ? 0 : split[(size_t)it.n * (W + 1) + (size_t)i];
-            if (ks == 255) { merged[it.n] = 1; out[n_out++] = it.n; continue; }              // the subtree as one leaf
-            if (t[it.n].count > 0 || i == 1 || ks == 0) { out[n_out++] = it.n; continue; }   // a leaf, or a wide node of its own
+            if (t[it.n].count > 0 || i == 1 || ks == 0) { out[n_out++] = it.n; continue; }      // a leaf, or a wide node of its own
             const uint32_t l = t[it.n].left_first;
             stack[sp++] = Item{l + 1, i - ks}; stack[sp++] = Item{l, ks};
         }
