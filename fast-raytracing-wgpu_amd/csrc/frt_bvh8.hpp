@@ -145,10 +145,6 @@ struct WideCollapse {
 inline void build_wide8(const std::vector<frt_bvh2_node>& t, Wide8& out) {
     out = Wide8{};
     if (t.empty()) return;
-    auto half_area = [&](uint32_t ni) {
-        const float dx = t[ni].bmax[0] - t[ni].bmin[0], dy = t[ni].bmax[1] - t[ni].bmin[1], dz = t[ni].bmax[2] - t[ni].bmin[2];
-        return dx * dy + dy * dz + dz * dx;
-    };
     struct Kids { uint32_t c[8]; int n; int slot[8]; };
     // 1. collapse: WideCollapse above
     WideCollapse dp(t, 8);

@@ -77,7 +77,28 @@ struct GSlots { uint32_t g, gprev, aux; };   // physical sets: this frame's G-bu
 static const int kPending = 2;               // pending ray-count sets / T-trace events: consecutive speculated frames alternate (with three G-buffer sets
                                              // T-trace(f+1) may start before T-merge(f) has committed the counts of T-trace(f))
 enum { C_STAGE = 0, C_HALO = 8, C_PENDING = 9, C_COUNT = 9 + 4 * kPending };   // a pending set of four per speculated frame in flight
-static const int kTileStateWords = 8;      // per traced stage (frt_kernels.hip: TileOrder uses 6)
+#if FRT_EXPERIMENTS
+static const int kTileStateWords = 8;      // per traced stage (experiments/frt_experiment_kernels.hpp: TileOrder uses 6)
+#endif
+
+#if FRT_EXPERIMENTS
+// Everything the measured-and-not-kept kernel designs (csrc/experiments/frt_experiment_kernels.hpp) need in a renderer: their state, their FRT_*
+// environment knobs, their allocations. Compiled into lib/libfrt_exp.so only (`make experiments`); the product library has none of it.
+struct ExpState {
+    int spec_depth = kSpecDepth;           // frames speculated ahead (FRT_SPEC_DEPTH, 0 .. kSpecDepth)
+    long cont_grid = -1;                   // FRT_CONT_GRID: slots the spatial continuation grids cover at least (-1: half the stage's pixels)
+    uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state (FRT_TILE_ORDER=1), or null
+    bool wg_park = true;                   // pixel kernels reserve queue slots once per workgroup (FRT_WG_PARK=0: once per wave)
+    bool wavefront = false;                // ray-level wavefront (FRT_WAVEFRONT=1): per bounce depth a trace launch and a shade launch
+    uint32_t* d_wf_words[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint32_t* d_wf_items[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint32_t* d_wf_hits[2] = {nullptr, nullptr}; uint32_t* d_wf_counts = nullptr;   // per stage: records x 2, item lists x 2, hit buffer; 2 x 96 counters
+    bool stream_mode = false; uint32_t shade_min = 32, stream_slice = 8;   // stream kernel (resumable traversal) instead of continuation launches
+    bool refill = false; uint32_t refill_min = 16;   // bounce kernel with lane refill (single cut) instead of continuation launches
+    bool resident = false;                 // traced stages through the resident kernels (BVH cached in LDS, persistent workgroups)
+    uint32_t res_nodes = 0; bool res_tris = false; uint32_t num_cus = 0, res_batch = 0;
+    uint32_t* d_work = nullptr;            // work counters of the resident launches: [stage 1|2][launch slot][2]
+};
+#endif
 
 struct frt_renderer {
     int device = 0;
@@ -86,7 +107,6 @@ struct frt_renderer {
     hipStream_t ahead = nullptr;           // FRT_FLAG_PIPELINE: G-buffer(f+1), T-trace(f+1)
     hipStream_t edge = nullptr;            // FRT_FLAG_PIPELINE, strips: the spatial pixel launches of the halo-dependent edge rows (beside the interior launch)
     hipStream_t edge2 = nullptr;           // ... the second edge of a middle strip: its launch runs beside the first one's instead of behind it
-    int spec_depth = kSpecDepth;           // frames speculated ahead (FRT_SPEC_DEPTH: experiment knob, 0 .. kSpecDepth)
     hipEvent_t ev_spix = nullptr, ev_tt[kPending] = {}, ev_tail = nullptr, ev_tm[2] = {nullptr, nullptr}, ev_edge = nullptr, ev_edge2 = nullptr, ev_edge_ready = nullptr;
     bool tail_pending = false;             // work enqueued on `ahead` that the main stream has not been ordered behind yet
     bool edge_in_flight = false, edge2_in_flight = false;
@@ -105,24 +125,16 @@ struct frt_renderer {
     uint32_t qcap = 0, qcap_max = 0;       // slots per queue; upper bound = every traced pixel parks
     uint32_t qslots[2][2] = {{0, 0}, {0, 0}};   // slots of each word buffer [stage][first | second buffer], derived from qcap (alloc_queues)
     uint64_t qbytes = 0;                   // device bytes of the word buffers
-    long cont_grid = -1;                   // FRT_CONT_GRID: slots the spatial continuation grids cover at least (-1: half the stage's pixels)
     bool qcap_fixed = false;               // capacity given by the caller: never grown
     uint32_t* d_qcount = nullptr;          // [stage 1|2][launch parity 0|1][kMaxCuts + 1] counters, then [stage] overflow counters
     uint32_t* h_qseen = nullptr; uint32_t* d_qseen = nullptr;   // one word of mapped host memory: set by a wave that found its queue full (ContQueue::seen)
     uint32_t qparity[2] = {0, 0};
     uint32_t ncuts = 2, cuts[kMaxCuts] = {3, 4, 0, 0};   // measured best on the Cornell Box
-    uint32_t* d_tiles = nullptr;           // per traced stage kTileStateWords words of sweep-direction state, or null
-    bool wg_park = true;                   // pixel kernels reserve queue slots once per workgroup (FRT_WG_PARK=0: once per wave, experiment knob)
     bool vote = false;                     // traced kernels with the voting BVH walk (set from the size of the scene's quad tree, upload_scene)
     uint32_t walk = kWalkQuad, wide_lds_bytes = 0;      // which tree the traced kernels walk (frt_kernels.hpp: kWalk*; upload_scene)
-    bool wavefront = false;                // ray-level wavefront (FRT_WAVEFRONT=1): per bounce depth a trace launch and a shade launch
-    uint32_t* d_wf_words[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; uint32_t* d_wf_items[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    uint32_t* d_wf_hits[2] = {nullptr, nullptr}; uint32_t* d_wf_counts = nullptr;   // per stage: records x 2, item lists x 2, hit buffer; 2 x 96 counters
-    bool stream_mode = false; uint32_t shade_min = 32, stream_slice = 8;   // stream kernel (resumable traversal) instead of continuation launches
-    bool refill = false; uint32_t refill_min = 16;   // bounce kernel with lane refill (single cut) instead of continuation launches
-    bool resident = false;                 // traced stages through the resident kernels (BVH cached in LDS, persistent workgroups)
-    uint32_t res_nodes = 0; bool res_tris = false; uint32_t num_cus = 0, res_batch = 0;
-    uint32_t* d_work = nullptr;            // work counters of the resident launches: [stage 1|2][launch slot][2]
+#if FRT_EXPERIMENTS
+    ExpState x;                            // lib/libfrt_exp.so only: state and FRT_* knobs of the measured-and-not-kept kernel designs (csrc/experiments/)
+#endif
     frt_stats stats{};
     struct Timed { hipEvent_t a, b; int slot; };
     std::vector<Timed> pending;
@@ -495,9 +507,11 @@ uint64_t frt_renderer_arena_bytes(uint32_t width, uint32_t height) { return aren
 
 static void free_queues(frt_renderer* r) {
     for (auto& st : r->d_qwords) for (uint32_t*& p : st) { if (p) (void)hipFree(p); p = nullptr; }
-    for (auto& st : r->d_wf_words) for (uint32_t*& p : st) { if (p) (void)hipFree(p); p = nullptr; }
-    for (auto& st : r->d_wf_items) for (uint32_t*& p : st) { if (p) (void)hipFree(p); p = nullptr; }
-    for (uint32_t*& p : r->d_wf_hits) { if (p) (void)hipFree(p); p = nullptr; }
+#if FRT_EXPERIMENTS
+    for (auto& st : r->x.d_wf_words) for (uint32_t*& p : st) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto& st : r->x.d_wf_items) for (uint32_t*& p : st) { if (p) (void)hipFree(p); p = nullptr; }
+    for (uint32_t*& p : r->x.d_wf_hits) { if (p) (void)hipFree(p); p = nullptr; }
+#endif
 }
 void frt_renderer_destroy(frt_renderer* r) {
     if (!r) return;
@@ -517,16 +531,20 @@ void frt_renderer_destroy(frt_renderer* r) {
     free_queues(r);
     if (r->d_qcount) (void)hipFree(r->d_qcount);
     if (r->h_qseen) (void)hipHostFree(r->h_qseen);
-    if (r->d_wf_counts) (void)hipFree(r->d_wf_counts);
-    if (r->d_tiles) (void)hipFree(r->d_tiles);
-    if (r->d_work) (void)hipFree(r->d_work);
+#if FRT_EXPERIMENTS
+    if (r->x.d_wf_counts) (void)hipFree(r->x.d_wf_counts);
+    if (r->x.d_tiles) (void)hipFree(r->x.d_tiles);
+    if (r->x.d_work) (void)hipFree(r->x.d_work);
+#endif
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
 
+#if FRT_EXPERIMENTS
 static const size_t kWfCounterWords = 1024;                        // per stage: record counts per pass and region, item counts at +512
 static const int kWorkSlots = 3 + kMaxCuts;                       // pixel launch (interior / whole), the two edge launches, one per continuation launch
 static const size_t kWorkWords = 2 * kWorkSlots * 2;               // [stage][slot]{next, ticket}
+#endif
 static const size_t kQoverflowAt = 2 * 2 * (kMaxCuts + 1);      // (even: the pointers in the overflow blocks are 8-byte aligned)
 static const size_t kQcountWords = kQoverflowAt + 2 * kOverflowBlockWords;   // [stage][parity][segment] counters + [stage] overflow blocks {count, pad, pointer to the mapped flag}
 static bool stage_is_cut(const frt_renderer* r) { return r->ncuts > 0 && r->cuts[0] < r->max_depth && !(r->flags & FRT_FLAG_COMPACTION); }
@@ -546,18 +564,20 @@ static int alloc_queues(frt_renderer* r, uint32_t cap) {
     r->qcap = cap;
     if (!stage_is_cut(r) || cap == 0) return FRT_OK;
     r->qbytes = 0;
-    if (r->wavefront) {
+#if FRT_EXPERIMENTS
+    if (r->x.wavefront) {
         r->qbytes = (uint64_t)2 * (2 * 44 + 2 * 2 + 7) * cap * sizeof(uint32_t);
         for (auto& q : r->qslots) q[0] = q[1] = cap;
         for (int st = 0; st < 2; ++st) {
             for (int k = 0; k < 2; ++k) {
-                HIP_TRY(hipMalloc((void**)&r->d_wf_words[st][k], (size_t)44 * cap * sizeof(uint32_t)));
-                HIP_TRY(hipMalloc((void**)&r->d_wf_items[st][k], (size_t)2 * cap * sizeof(uint32_t)));
+                HIP_TRY(hipMalloc((void**)&r->x.d_wf_words[st][k], (size_t)44 * cap * sizeof(uint32_t)));
+                HIP_TRY(hipMalloc((void**)&r->x.d_wf_items[st][k], (size_t)2 * cap * sizeof(uint32_t)));
             }
-            HIP_TRY(hipMalloc((void**)&r->d_wf_hits[st], (size_t)7 * cap * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&r->x.d_wf_hits[st], (size_t)7 * cap * sizeof(uint32_t)));
         }
         return FRT_OK;
     }
+#endif
     // `cap` is the first buffer of the spatial stage. Measured per pixel on the Cornell Box (FRT_DEBUG_QUEUES; cuts 3 and 4): the spatial stage
     // parks 0.165 paths at the first cut and 0.10 at the second, T-trace 0.108 and 0.049. The other three buffers are sized in that
     // proportion (x 1.0 / 0.6 / 0.65 / 0.3 of `cap`, itself 0.25 per pixel by default); any of them may overflow (paths finish in place) and
@@ -574,14 +594,83 @@ static int alloc_queues(frt_renderer* r, uint32_t cap) {
         }
     return FRT_OK;
 }
+#if FRT_EXPERIMENTS
 static int init_tile_state(frt_renderer* r) {
-    if (!r->d_tiles) return FRT_OK;
+    if (!r->x.d_tiles) return FRT_OK;
     uint32_t init[2 * kTileStateWords] = {0};
     init[0] = 1u; init[kTileStateWords] = 1u;   // first launch: bottom tile row first (floors cost more than ceilings and skies)
-    HIP_TRY(hipMemcpyAsync(r->d_tiles, init, sizeof(init), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipMemcpyAsync(r->x.d_tiles, init, sizeof(init), hipMemcpyHostToDevice, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return FRT_OK;
 }
+// The experiment knobs and allocations of a renderer, in the two places renderer_init needs them: phase 0 inside the block that decides the cuts
+// (before the queues are sized), phase 1 behind the scene upload.
+static int exp_init(frt_renderer* r, int phase) {
+    ExpState& x = r->x;
+    if (phase == 0) {
+        if (const char* e = getenv("FRT_CUTS")) {   // comma-separated ascending depths, "0" = never cut
+            r->ncuts = 0;
+            uint32_t last = 0;
+            for (const char* p = e; *p && r->ncuts < (uint32_t)kMaxCuts;) {
+                char* end = nullptr;
+                const unsigned long v = strtoul(p, &end, 10);
+                if (end == p) break;                                   // not a number: stop parsing (never loops on "abc" or "3;5")
+                if (v >= 1 && v > last && v < 0xFFFFu) { r->cuts[r->ncuts++] = (uint32_t)v; last = (uint32_t)v; }   // ascending only; others are skipped
+                p = end;
+                if (*p == ',') ++p; else break;
+            }
+        }
+        if (const char* e = getenv("FRT_WAVEFRONT")) {      // the ray-level wavefront needs the cut at depth 1
+            x.wavefront = atoi(e) != 0 && !(r->flags & FRT_FLAG_COMPACTION) && r->max_depth > 1 && r->max_depth < 31;
+            if (x.wavefront) { r->ncuts = 1; r->cuts[0] = 1; }
+        }
+        HIP_TRY(hipMalloc((void**)&x.d_wf_counts, 2 * kWfCounterWords * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(x.d_wf_counts, 0, 2 * kWfCounterWords * sizeof(uint32_t), r->stream));
+        // Sweep direction of the tile rows (experiments/frt_experiment_kernels.hpp: TileOrder; resident pixel kernels only): FRT_TILE_ORDER=1
+        if (const char* e = getenv("FRT_TILE_ORDER"); e && atoi(e) != 0) {
+            HIP_TRY(hipMalloc((void**)&x.d_tiles, 2 * kTileStateWords * sizeof(uint32_t)));
+            const int rc = init_tile_state(r);
+            if (rc) return rc;
+        }
+        return FRT_OK;
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+    x.num_cus = (uint32_t)prop.multiProcessorCount;
+    resident_plan(r->sv, x.res_nodes, x.res_tris);
+    if (const char* e = getenv("FRT_RESIDENT")) x.resident = atoi(e) != 0 && x.res_nodes > 0 && !(r->flags & FRT_FLAG_COMPACTION);
+    if (const char* e = getenv("FRT_STREAM")) { x.stream_mode = atoi(e) != 0; if (atoi(e) > 1) x.shade_min = (uint32_t)std::min(64, atoi(e)); }   // n > 1 = shade_min
+    if (const char* e = getenv("FRT_WG_PARK")) x.wg_park = atoi(e) != 0;
+    if (const char* e = getenv("FRT_CONT_GRID")) x.cont_grid = std::max(0l, atol(e));
+    if (const char* e = getenv("FRT_STREAM_SLICE")) x.stream_slice = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("FRT_REFILL")) { x.refill = atoi(e) != 0; if (atoi(e) > 1) x.refill_min = (uint32_t)std::min(64, atoi(e)); }   // 0 off, 1 on, n > 1: refill when >= n lanes are free
+    if ((x.refill || x.stream_mode) && !getenv("FRT_CUTS") && r->ncuts > 1) r->ncuts = 1;   // (those kernels replace the continuation launches of a single cut)
+    if (const char* e = getenv("FRT_RES_BATCH")) x.res_batch = (uint32_t)atoi(e);      // tiles per fetch (1, 2, 4)
+    if (const char* e = getenv("FRT_RES_TRIS")) { if (atoi(e) == 0) x.res_tris = false; }   // triangles from L2
+    HIP_TRY(hipMalloc((void**)&x.d_work, kWorkWords * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(x.d_work, 0, kWorkWords * sizeof(uint32_t), r->stream));
+    return FRT_OK;
+}
+// The experiment fields of a stage's launch description (frt_kernels.hpp: TraceLaunch).
+static void exp_fill_launch(frt_renderer* r, int stage, bool with_tile_state, TraceLaunch& L, int work_slot, bool cut) {
+    const ExpState& x = r->x;
+    L.wg_park = x.wg_park;
+    L.refill = x.refill; L.refill_min = x.refill_min; L.stream = x.stream_mode; L.shade_min = x.shade_min; L.slice = x.stream_slice;
+    L.resident = x.resident; L.res_nodes = x.res_nodes; L.res_tris = x.res_tris; L.num_cus = x.num_cus; L.res_batch = x.res_batch;
+    L.work = x.d_work + ((size_t)(stage - 1) * kWorkSlots + (size_t)work_slot) * 2;
+    if (x.cont_grid >= 0) L.grid_min_slots = (uint32_t)x.cont_grid;   // (FRT_CONT_GRID, read at creation)
+    L.tile_state = (with_tile_state && x.d_tiles) ? x.d_tiles + (size_t)(stage - 1) * kTileStateWords : nullptr;
+    if (x.wavefront && cut) {
+        L.wavefront = true;
+        for (int k = 0; k < 2; ++k) { L.wf_words[k] = x.d_wf_words[stage - 1][k]; L.wf_items[k] = x.d_wf_items[stage - 1][k]; }
+        L.wf_hits = x.d_wf_hits[stage - 1];
+        L.qwords[0] = L.wf_words[0]; L.qwords[1] = nullptr;
+        L.counts = x.d_wf_counts + (size_t)(stage - 1) * kWfCounterWords;      // cleared by the host before the stage's pixel launch
+        L.zero_counts = nullptr;
+        L.slice = x.stream_slice;
+    }
+}
+#endif
 
 static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_opts* o) {
     int ndev = 0;
@@ -604,7 +693,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
         for (hipEvent_t* e : {&r->ev_spix, &r->ev_tail, &r->ev_tm[0], &r->ev_tm[1], &r->ev_edge, &r->ev_edge2, &r->ev_edge_ready}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
         for (hipEvent_t& e : r->ev_tt) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 #if FRT_EXPERIMENTS
-        if (const char* e = getenv("FRT_SPEC_DEPTH")) r->spec_depth = std::max(0, std::min(kSpecDepth, atoi(e)));
+        if (const char* e = getenv("FRT_SPEC_DEPTH")) r->x.spec_depth = std::max(0, std::min(kSpecDepth, atoi(e)));
 #endif
     }
     r->arena_bytes = arena_layout(r->W, r->H, r->off);
@@ -644,22 +733,7 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
             }
         }
 #if FRT_EXPERIMENTS
-        if (const char* e = getenv("FRT_CUTS")) {   // comma-separated ascending depths, "0" = never cut
-            r->ncuts = 0;
-            uint32_t last = 0;
-            for (const char* p = e; *p && r->ncuts < (uint32_t)kMaxCuts;) {
-                char* end = nullptr;
-                const unsigned long v = strtoul(p, &end, 10);
-                if (end == p) break;                                   // not a number: stop parsing (never loops on "abc" or "3;5")
-                if (v >= 1 && v > last && v < 0xFFFFu) { r->cuts[r->ncuts++] = (uint32_t)v; last = (uint32_t)v; }   // ascending only; others are skipped
-                p = end;
-                if (*p == ',') ++p; else break;
-            }
-        }
-        if (const char* e = getenv("FRT_WAVEFRONT")) {      // the ray-level wavefront needs the cut at depth 1
-            r->wavefront = atoi(e) != 0 && !(r->flags & FRT_FLAG_COMPACTION) && r->max_depth > 1 && r->max_depth < 31;
-            if (r->wavefront) { r->ncuts = 1; r->cuts[0] = 1; }
-        }
+        { const int rc_ = exp_init(r, 0); if (rc_) return rc_; }      // FRT_CUTS, FRT_WAVEFRONT, FRT_TILE_ORDER: before the queues are sized
 #endif
         r->qcap_max = r->W * std::min(r->H, (r->re - r->rb) + 2u * kHaloSpatial);   // every traced pixel parks
         // Default capacity from the share of paths that reach the first cut (Cornell Box, oracle counts per pixel: 0.65 / 0.50 / 0.11
@@ -674,8 +748,6 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
 #endif
         int rc = alloc_queues(r, cap);
         if (rc) return rc;
-        HIP_TRY(hipMalloc((void**)&r->d_wf_counts, 2 * kWfCounterWords * sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(r->d_wf_counts, 0, 2 * kWfCounterWords * sizeof(uint32_t), r->stream));
         HIP_TRY(hipMalloc((void**)&r->d_qcount, kQcountWords * sizeof(uint32_t)));
         // (no mapped host memory -> no flag: the queues are then grown by frt_renderer_stats alone, as before)
         if (hipHostMalloc((void**)&r->h_qseen, sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
@@ -683,40 +755,15 @@ static int renderer_init(frt_renderer* r, const frt_scene* s, const frt_render_o
             if (hipHostGetDevicePointer((void**)&r->d_qseen, r->h_qseen, 0) != hipSuccess) { (void)hipHostFree(r->h_qseen); r->h_qseen = nullptr; r->d_qseen = nullptr; }
         } else { r->h_qseen = nullptr; (void)hipGetLastError(); }
         { int rc_ = clear_queue_counters(r); if (rc_) return rc_; }
-#if FRT_EXPERIMENTS
-        // Sweep direction of the tile rows (experiments/frt_experiment_kernels.hpp: TileOrder; resident pixel kernels only): FRT_TILE_ORDER=1
-        if (const char* e = getenv("FRT_TILE_ORDER"); e && atoi(e) != 0) {
-            HIP_TRY(hipMalloc((void**)&r->d_tiles, 2 * kTileStateWords * sizeof(uint32_t)));
-            rc = init_tile_state(r);
-            if (rc) return rc;
-        }
-#endif
     }
     HIP_TRY(hipMemsetAsync(r->arena, 0, r->arena_bytes, r->stream));   // wgpu zero-initialises textures and buffers
     if (r->extras) HIP_TRY(hipMemsetAsync(r->extras, 0, r->extras_bytes, r->stream));
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, C_COUNT * sizeof(unsigned long long), r->stream));
     int rc = upload_scene(r, s->b);
     if (rc) return rc;
-    {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, r->device));
-        r->num_cus = (uint32_t)prop.multiProcessorCount;
 #if FRT_EXPERIMENTS
-        // the experimental kernel forms (experiments/frt_experiment_kernels.hpp) and their knobs
-        resident_plan(r->sv, r->res_nodes, r->res_tris);
-        if (const char* e = getenv("FRT_RESIDENT")) r->resident = atoi(e) != 0 && r->res_nodes > 0 && !(r->flags & FRT_FLAG_COMPACTION);
-        if (const char* e = getenv("FRT_STREAM")) { r->stream_mode = atoi(e) != 0; if (atoi(e) > 1) r->shade_min = (uint32_t)std::min(64, atoi(e)); }   // n > 1 = shade_min
-        if (const char* e = getenv("FRT_WG_PARK")) r->wg_park = atoi(e) != 0;
-        if (const char* e = getenv("FRT_CONT_GRID")) r->cont_grid = std::max(0l, atol(e));
-        if (const char* e = getenv("FRT_STREAM_SLICE")) r->stream_slice = (uint32_t)std::max(1, atoi(e));
-        if (const char* e = getenv("FRT_REFILL")) { r->refill = atoi(e) != 0; if (atoi(e) > 1) r->refill_min = (uint32_t)std::min(64, atoi(e)); }   // 0 off, 1 on, n > 1: refill when >= n lanes are free
-        if ((r->refill || r->stream_mode) && !getenv("FRT_CUTS") && r->ncuts > 1) r->ncuts = 1;   // (those kernels replace the continuation launches of a single cut)
-        if (const char* e = getenv("FRT_RES_BATCH")) r->res_batch = (uint32_t)atoi(e);      // tiles per fetch (1, 2, 4)
-        if (const char* e = getenv("FRT_RES_TRIS")) { if (atoi(e) == 0) r->res_tris = false; }   // triangles from L2
+    { const int rc_ = exp_init(r, 1); if (rc_) return rc_; }      // the experimental kernel forms' knobs and work counters
 #endif
-        HIP_TRY(hipMalloc((void**)&r->d_work, kWorkWords * sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(r->d_work, 0, kWorkWords * sizeof(uint32_t), r->stream));
-    }
     HIP_TRY(hipStreamSynchronize(r->stream));
     return FRT_OK;
 }
@@ -763,12 +810,9 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
 // run beside the interior one); the continuation launches use the pairs behind them.
 static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, TraceLaunch& L, int work_slot = 0) {
     memset(&L, 0, sizeof(L));
-    L.wg_park = r->wg_park;
+    L.wg_park = true;
     L.vote = r->vote;
     L.walk = r->walk; L.wide_lds_bytes = r->wide_lds_bytes;
-    L.refill = r->refill; L.refill_min = r->refill_min; L.stream = r->stream_mode; L.shade_min = r->shade_min; L.slice = r->stream_slice;
-    L.resident = r->resident; L.res_nodes = r->res_nodes; L.res_tris = r->res_tris; L.num_cus = r->num_cus; L.res_batch = r->res_batch;
-    L.work = r->d_work + ((size_t)(stage - 1) * kWorkSlots + (size_t)work_slot) * 2;
     const bool cut = stage_is_cut(r) && r->qcap > 0;
     L.ncuts = cut ? r->ncuts : 0u;
     for (int k = 0; k < kMaxCuts; ++k) L.cuts[k] = r->cuts[k];
@@ -783,18 +827,12 @@ static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, Tr
     // 1.92 / 1.92 / 1.92; no effect on one stream, none for the T-trace launches on the ahead stream): while the grid is still being
     // dispatched the main stream keeps its turn at the dispatcher beside the next frame's T-trace pixel kernel (profiles/r2_schedule_notes.md).
     L.grid_min_slots = (stage == 2 && r->pipeline()) ? (uint32_t)std::min<uint64_t>(r->qcap_max, (uint64_t)r->W * (r->re - r->rb) / 2u) : 0u;
-    if (r->cont_grid >= 0) L.grid_min_slots = (uint32_t)r->cont_grid;   // (FRT_CONT_GRID: experiment knob, read at creation)
     L.overflow = r->d_qcount + kQoverflowAt + (size_t)(stage - 1) * kOverflowBlockWords;
-    L.tile_state = (with_tile_state && r->d_tiles) ? r->d_tiles + (size_t)(stage - 1) * kTileStateWords : nullptr;
-    if (r->wavefront && cut) {
-        L.wavefront = true;
-        for (int k = 0; k < 2; ++k) { L.wf_words[k] = r->d_wf_words[stage - 1][k]; L.wf_items[k] = r->d_wf_items[stage - 1][k]; }
-        L.wf_hits = r->d_wf_hits[stage - 1];
-        L.qwords[0] = L.wf_words[0]; L.qwords[1] = nullptr;
-        L.counts = r->d_wf_counts + (size_t)(stage - 1) * kWfCounterWords;      // cleared by the host before the stage's pixel launch
-        L.zero_counts = nullptr;
-        L.slice = r->stream_slice;
-    }
+#if FRT_EXPERIMENTS
+    exp_fill_launch(r, stage, with_tile_state, L, work_slot, cut);
+#else
+    (void)with_tile_state; (void)work_slot;
+#endif
 }
 
 // G-buffer + T-trace over their rows on stream `q`; pending_set >= 0: count the rays in that pending set (speculative work).
@@ -819,7 +857,9 @@ static int launch_g_and_trace(frt_renderer* r, FrameView fv, hipStream_t q, bool
         trace_launch_of(r, 1, true, L);
         frt_renderer::Timed t{};
         if (timed) { int rc = timer_begin(r, t, 1, q); if (rc) return rc; }
+#if FRT_EXPERIMENTS
         if (L.wavefront) HIP_TRY(hipMemsetAsync(L.counts, 0, kWfCounterWords * sizeof(uint32_t), q));
+#endif
         HIP_TRY(launch_trace_pixels(1, r->sv, fv, q, L));
         if (trace_has_continuations(L, r->max_depth)) HIP_TRY(launch_trace_continuations(1, r->sv, fv, q, L));
         if (timed) { int rc = timer_end(r, t, q); if (rc) return rc; }
@@ -924,7 +964,12 @@ static int open_frame(frt_renderer* r, const frt_camera_uniform* cam) {
 // by that frame's spatial and post stages and, as `prev`, by this T-merge — all on the main stream before the event).
 static int launch_speculation(frt_renderer* r, const frt_camera_uniform* cam) {
     if (!r->pipeline() || !r->camera_static || !r->tm_done) return FRT_OK;
-    while ((int)r->specs.size() < r->spec_depth) {
+#if FRT_EXPERIMENTS
+    const int spec_depth = r->x.spec_depth;
+#else
+    const int spec_depth = kSpecDepth;
+#endif
+    while ((int)r->specs.size() < spec_depth) {
         frt_renderer::Spec sp;
         sp.cam = next_static_camera(r->specs.empty() ? *cam : r->specs.back().cam);
         sp.frame = (r->specs.empty() ? r->frame_count : r->specs.back().frame) + 1u;
@@ -1024,7 +1069,9 @@ static int render_phases_impl(frt_renderer* r, const frt_camera_uniform* cam, in
             spatial_inner_rows(r, y0, y1, ia, ib);
             if ((sp & FRT_PHASE_SPATIAL_INNER) && !r->s_inner_done) {
                 trace_launch_of(r, 2, true, L);
+#if FRT_EXPERIMENTS
                 if (L.wavefront) HIP_TRY(hipMemsetAsync(L.counts, 0, kWfCounterWords * sizeof(uint32_t), r->stream));   // (whole-frame renderers: the interior launch is the first of the stage)
+#endif
                 fv.y0 = ia; fv.y1 = ib;
                 HIP_TRY(launch_trace_pixels(2, r->sv, fv, r->stream, L));
                 r->s_inner_done = true;
@@ -1053,7 +1100,11 @@ static int render_phases_impl(frt_renderer* r, const frt_camera_uniform* cam, in
                     if (e[1] <= e[0]) continue;
                     L.zero_counts = need_clear ? zc : nullptr;
                     need_clear = false;
-                    L.work = r->d_work + ((size_t)kWorkSlots + (size_t)this_slot) * 2;     // stage 2, its own counters
+#if FRT_EXPERIMENTS
+                    L.work = r->x.d_work + ((size_t)kWorkSlots + (size_t)this_slot) * 2;     // stage 2, its own counters (resident kernels)
+#else
+                    (void)this_slot;
+#endif
                     fv.y0 = e[0]; fv.y1 = e[1];
                     HIP_TRY(launch_trace_pixels(2, r->sv, fv, (two_edges && this_slot == 2) ? r->edge2 : q, L));
                 }
@@ -1146,10 +1197,14 @@ int frt_renderer_clear(frt_renderer* r) {
     if (r->extras) HIP_TRY(hipMemsetAsync(r->extras, 0, r->extras_bytes, r->stream));
     HIP_TRY(hipMemsetAsync(r->d_counters, 0, C_COUNT * sizeof(unsigned long long), r->stream));
     { int rc_ = clear_queue_counters(r); if (rc_) return rc_; }
-    HIP_TRY(hipMemsetAsync(r->d_work, 0, kWorkWords * sizeof(uint32_t), r->stream));
+#if FRT_EXPERIMENTS
+    HIP_TRY(hipMemsetAsync(r->x.d_work, 0, kWorkWords * sizeof(uint32_t), r->stream));
+#endif
     HIP_TRY(hipStreamSynchronize(r->stream));
+#if FRT_EXPERIMENTS
     rc = init_tile_state(r);
     if (rc) return rc;
+#endif
     r->frame_count = 0;
     r->failed = false;
     r->frame_open = false; r->specs.clear(); r->have_last_cam = false; r->camera_static = false;
