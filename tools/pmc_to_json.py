@@ -2,7 +2,7 @@
 into the JSON bench.py reads for its roofline block: per-kernel per-launch means, HBM bytes and VALU wave-instructions per frame, the
 calibrated issue cost, and the hashes of the device sources / code objects they were measured on (bench.py flags the numbers `stale` when neither matches).
 Run HERE (the repository with .git), after the gpurun call that produced the passes:
-    python tools/pmc_to_json.py r3 > profiles/r3_pmc.json"""
+    python tools/pmc_to_json.py r4 > profiles/r4_pmc.json"""
 import collections, csv, glob, json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

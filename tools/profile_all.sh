@@ -3,7 +3,7 @@
 #   1. rocprofv3 --kernel-trace --stats of the default bench command      -> gpurun_out/prof_<tag>/…kernel_stats.csv
 #   2. separate --pmc passes (never combined with other trace domains)     -> gpurun_out/pmc_<tag>_*/…counter_collection.csv
 #   3. the bench line itself, with the CPU baseline                        -> gpurun_out/bench_<tag>.json
-# then prints tools/pmc_summary.py over the PMC passes. Afterwards, in the repository: python tools/pmc_to_json.py <tag> > profiles/r3_pmc.json
+# then prints tools/pmc_summary.py over the PMC passes. Afterwards, in the repository: python tools/pmc_to_json.py <tag> > profiles/<tag>_pmc.json
 # (bench.py's roofline block reads it) and copy what should be judged into profiles/.
 set -o pipefail
 TAG=${1:-run}
