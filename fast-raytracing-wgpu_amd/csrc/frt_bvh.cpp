@@ -286,6 +286,14 @@ static void build_quad_nodes(SceneBuilder& b, int dp = FRT_QUAD_DP ? 2 : 0) {   
     if (b.quad_stack_need > (uint32_t)kStackDepth - 1u) b.error = "quad tree exceeds the traversal stack";   // (cannot happen: see above; the last row of the LDS array is not a stack entry, frt_kernels.hip: kMiscRow)
 }
 
+void SceneBuilder::ensure_wide8() const {
+    if (wide8_built || !built) return;
+    build_wide8(bvh2, wide8);
+    tri_slots8.clear();
+    if (wide8.ok) { tri_slots8.resize(wide8.tri_order.size()); for (size_t i = 0; i < tri_slots8.size(); ++i) tri_slots8[i] = tri_slots[wide8.tri_order[i]]; }
+    wide8_built = true;
+}
+
 void SceneBuilder::build_gpu_layout() {
     pair_nodes.clear(); tri_slots.clear(); instances_dev.clear(); shade_tris.clear();
     if (!error.empty()) return;
@@ -346,9 +354,7 @@ void SceneBuilder::build_gpu_layout() {
     }
     quantize_pair_nodes(*this);
     build_quad_nodes(*this);
-    build_wide8(bvh2, wide8);
-    tri_slots8.clear();
-    if (wide8.ok) { tri_slots8.resize(wide8.tri_order.size()); for (size_t i = 0; i < tri_slots8.size(); ++i) tri_slots8[i] = tri_slots[wide8.tri_order[i]]; }
+    wide8 = Wide8{}; tri_slots8.clear(); wide8_built = false;      // (built on first use: ensure_wide8)
     // shading records: the instance -> mesh -> index -> attribute chain of gbuffer.wgsl:129-145, flattened per triangle
     shade_tris.assign(tris.size(), ShadeTri{});
     for (size_t id = 0; id < tris.size(); ++id) {

@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(kBlock) post_jitter_kernel(FrameView fv) {
 #endif
 #if FRT_EXPERIMENTS
 #include "experiments/frt_experiment_kernels.hpp"      // lib/libfrt_exp.so only (`make experiments`)
+#include "experiments/frt_round4_walks.hpp"            // ... round 4: collective walks (wg_trace)
 #endif
 
 static dim3 grid_for(const FrameView& fv) { return dim3((fv.W + 15u) / 16u, (fv.y1 - fv.y0 + 15u) / 16u, 1u); }
@@ -344,8 +345,11 @@ static uint32_t first_cut(const TraceLaunch& L, const FrameView& fv) { return L.
 
 hipError_t launch_gbuffer(const SceneView& sc, const FrameView& fv, hipStream_t stream, uint32_t walk) {
     if (empty_rows(fv)) return hipSuccess;
-    if (walk >= (uint32_t)kWalkWide) hipLaunchKernelGGL(gbuffer_kernel<kWalkWide>, grid_for(fv), dim3(kBlock), 0, stream, sc, fv);
-    else hipLaunchKernelGGL(gbuffer_kernel<kWalkQuad>, grid_for(fv), dim3(kBlock), 0, stream, sc, fv);
+#if FRT_EXPERIMENTS
+    if (walk == (uint32_t)kWalkWide || walk == (uint32_t)kWalkWideLds) { hipLaunchKernelGGL(gbuffer_kernel<kWalkWide>, grid_for(fv), dim3(kBlock), 0, stream, sc, fv); return hipGetLastError(); }
+#endif
+    (void)walk;
+    hipLaunchKernelGGL(gbuffer_kernel<kWalkQuad>, grid_for(fv), dim3(kBlock), 0, stream, sc, fv);
     return hipGetLastError();
 }
 hipError_t launch_post(const FrameView& fv, hipStream_t stream) {
@@ -375,13 +379,19 @@ hipError_t launch_trace_pixels(int stage, const SceneView& sc, const FrameView& 
     if (L.resident) return exp_launch_resident_pixels(stage, sc, fv, stream, L);
 #endif
     auto go = [&](auto kernel, uint32_t lds = 0u) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), L.zero_counts, L.wg_park); };
-    if (stage == 1) {
-        if (L.walk == (uint32_t)kWalkWideLds) go(pixel_kernel<1, kWalkWideLds>, L.wide_lds_bytes); else if (L.walk == (uint32_t)kWalkWide) go(pixel_kernel<1, kWalkWide>);
-        else if (L.vote) go(pixel_kernel<1, 1>); else go(pixel_kernel<1, 0>);
-    } else {
-        if (L.walk == (uint32_t)kWalkWideLds) go(pixel_kernel<2, kWalkWideLds>, L.wide_lds_bytes); else if (L.walk == (uint32_t)kWalkWide) go(pixel_kernel<2, kWalkWide>);
-        else if (L.vote) go(pixel_kernel<2, 1>); else go(pixel_kernel<2, 0>);
+#if FRT_EXPERIMENTS
+    if (L.walk == (uint32_t)kWalkQuadWg) {      // collective walks: dynamic LDS = stack rows + exchange rows
+        const uint32_t lds = (L.wg_rows + (uint32_t)kXRows) * (uint32_t)kBlock * 4u;
+        auto gw = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, sc, fv, queue_of(L, 0), first_cut(L, fv), L.zero_counts, L.wg_rows); };
+        if (stage == 1) { if (L.vote) gw(pixel_kernel_wg<1, true>); else gw(pixel_kernel_wg<1, false>); }
+        else { if (L.vote) gw(pixel_kernel_wg<2, true>); else gw(pixel_kernel_wg<2, false>); }
+        return hipGetLastError();
     }
+    if (L.walk == (uint32_t)kWalkWideLds) { if (stage == 1) go(pixel_kernel<1, kWalkWideLds>, L.wide_lds_bytes); else go(pixel_kernel<2, kWalkWideLds>, L.wide_lds_bytes); return hipGetLastError(); }
+    if (L.walk == (uint32_t)kWalkWide) { if (stage == 1) go(pixel_kernel<1, kWalkWide>); else go(pixel_kernel<2, kWalkWide>); return hipGetLastError(); }
+#endif
+    if (stage == 1) { if (L.vote) go(pixel_kernel<1, 1>); else go(pixel_kernel<1, 0>); }
+    else { if (L.vote) go(pixel_kernel<2, 1>); else go(pixel_kernel<2, 0>); }
     return hipGetLastError();
 }
 bool trace_has_continuations(const TraceLaunch& L, uint32_t max_depth) { return L.ncuts > 0 && L.cuts[0] < max_depth; }
@@ -397,13 +407,19 @@ hipError_t launch_trace_continuations(int stage, const SceneView& sc, const Fram
         const dim3 cgrid((gslots + (uint32_t)kBlock - 1u) / (uint32_t)kBlock);
         const uint32_t d0 = L.cuts[k], d1 = (k + 1 < L.ncuts && L.cuts[k + 1] < fv.max_depth) ? L.cuts[k + 1] : fv.max_depth;
         auto go = [&](auto kernel, uint32_t lds = 0u) { hipLaunchKernelGGL(kernel, cgrid, dim3(kBlock), lds, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1); };
-        if (stage == 1) {
-            if (L.walk == (uint32_t)kWalkWideLds) go(continue_kernel<1, kWalkWideLds>, L.wide_lds_bytes); else if (L.walk == (uint32_t)kWalkWide) go(continue_kernel<1, kWalkWide>);
-            else if (L.vote) go(continue_kernel<1, 1>); else go(continue_kernel<1, 0>);
-        } else {
-            if (L.walk == (uint32_t)kWalkWideLds) go(continue_kernel<2, kWalkWideLds>, L.wide_lds_bytes); else if (L.walk == (uint32_t)kWalkWide) go(continue_kernel<2, kWalkWide>);
-            else if (L.vote) go(continue_kernel<2, 1>); else go(continue_kernel<2, 0>);
+#if FRT_EXPERIMENTS
+        if (L.walk == (uint32_t)kWalkQuadWg) {
+            const uint32_t lds = (L.wg_rows + (uint32_t)kXRows) * (uint32_t)kBlock * 4u;
+            auto gw = [&](auto kernel) { hipLaunchKernelGGL(kernel, cgrid, dim3(kBlock), lds, stream, sc, fv, queue_of(L, k), queue_of(L, k + 1), d0, d1, L.wg_rows); };
+            if (stage == 1) { if (L.vote) gw(continue_kernel_wg<1, true>); else gw(continue_kernel_wg<1, false>); }
+            else { if (L.vote) gw(continue_kernel_wg<2, true>); else gw(continue_kernel_wg<2, false>); }
+            continue;
         }
+        if (L.walk == (uint32_t)kWalkWideLds) { if (stage == 1) go(continue_kernel<1, kWalkWideLds>, L.wide_lds_bytes); else go(continue_kernel<2, kWalkWideLds>, L.wide_lds_bytes); continue; }
+        if (L.walk == (uint32_t)kWalkWide) { if (stage == 1) go(continue_kernel<1, kWalkWide>); else go(continue_kernel<2, kWalkWide>); continue; }
+#endif
+        if (stage == 1) { if (L.vote) go(continue_kernel<1, 1>); else go(continue_kernel<1, 0>); }
+        else { if (L.vote) go(continue_kernel<2, 1>); else go(continue_kernel<2, 0>); }
     }
     return hipGetLastError();
 }

@@ -8,7 +8,7 @@ namespace frt {
 // every segment has its OWN counter (counts[0 .. ncuts], zero before the stage runs), so a buffer that is written again two launches
 // later starts from slot 0. `zero_counts`: the counter set of this stage's NEXT launch, cleared in passing by the pixel kernel.
 static constexpr int kMaxCuts = 4;
-enum { kWalkQuad = 0, kWalkWide = 2, kWalkWideLds = 3 };      // (1 = the quad walk with the voting loop: TraceLaunch::vote)
+enum { kWalkQuad = 0, kWalkWide = 2, kWalkWideLds = 3, kWalkQuadWg = 4 };      // (1 = the quad walk with the voting loop: TraceLaunch::vote; kWalkQuadWg: the quad walk, a workgroup's rays re-dealt to dense direction-sorted waves: frt_kernels.hip: wg_trace)
 #ifndef FRT_EXPERIMENTS
 #define FRT_EXPERIMENTS 0
 #endif
@@ -21,6 +21,7 @@ struct TraceLaunch {
     bool vote;      // the kernels whose BVH walk votes for its next step (frt_trace.hpp: trace4<ANY, VOTE>): scenes with a deep tree
     uint32_t walk;  // which tree the traced kernels walk: kWalkQuad (trace4; `vote` picks its loop), kWalkWide (trace8, nodes read from HBM), kWalkWideLds (trace8, the whole 8-wide tree copied into every workgroup's LDS: wide_lds_bytes of dynamic LDS)
     uint32_t wide_lds_bytes;
+    uint32_t wg_rows;   // kWalkQuadWg: stack rows of a workgroup's dynamic LDS (the quad tree's stack need + the shared row)
 #if FRT_EXPERIMENTS
     // lib/libfrt_exp.so only (csrc/experiments/frt_experiment_kernels.hpp): the measured-and-not-kept kernel designs
     uint32_t* tile_state;   // the stage's sweep-direction state (TileOrder) or null = tile rows top to bottom

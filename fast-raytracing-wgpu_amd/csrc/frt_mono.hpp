@@ -52,6 +52,48 @@ FRT_HD f3 nee(Ctx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_color,
     return splat3(0.0f);
 }
 
+// ---- one bounce with its two rays pulled apart (the form the stream kernel runs, frt_kernels.hip) -----------------------------
+// path_loop traces the closest-hit ray, shades, traces the shadow ray of the next-event estimate in the middle of the shading, and
+// goes on. Here one iteration is cut at its rays:   [closest-hit ray]  ->  bounce_shade  ->  [shadow ray]  ->  add the estimate
+// bounce_shade does everything else of the iteration — hit, material, emission, light hit, the estimate's value (as if unoccluded), BSDF
+// sample, the next iteration's roulette — and hands back the shadow ray with the value to add when it is unoccluded. Same operations
+// on the same operands as path_loop: the estimate is a pure function of the hit (evaluating it before the visibility test instead of
+// after changes nothing), it is the only addition to `accumulated` between the light-hit test and the end of the iteration, nothing
+// after it reads `accumulated`, and no ray draws a random number, so the rand() sequence is the reference's.
+// dark: what path_loop adds when the estimate is NOT lit — zero, or zero times the throughput (NaN where the throughput is inf / NaN: the
+// reference's GGX term overflows on the roughness-0.01 box, DESIGN.md §3), so that even those paths stay bit-identical.
+struct ShadowReq { bool want; bool add_now; f3 o, d; float tmin, tmax; f3 contrib, dark; };
+
+template <int VARIANT, class Ctx>
+FRT_HD void nee_request(Ctx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_color, f3 throughput, ShadowReq& req) {   // nee() + eval_direct_lighting() up to the ray
+    req.want = false; req.add_now = false; req.contrib = splat3(0.0f); req.dark = splat3(0.0f);
+    req.o = splat3(0.0f); req.d = splat3(0.0f); req.tmin = 0.0f; req.tmax = 0.0f;
+    uint32_t nl = c.fv.cam.num_lights;
+    if (nl == 0u) return;
+    uint32_t light_idx = (uint32_t)(c.rand() * (float)nl);
+    if (!(light_idx < nl)) return;
+    req.dark = splat3(0.0f) * throughput;      // from here on nee() returns eval_direct_lighting(...) * throughput
+    LightSmp ls = sample_light(c, light_idx);
+    float pdf_nee = ls.pdf * (1.0f / (float)nl);
+    float p_bsdf = eval_pdf(hit.ffnormal, normalize(ls.pos - hit.pos), wo, m, base_color);
+    float mis_weight_nee = pdf_nee / (pdf_nee + p_bsdf);
+    float weight = mis_weight_nee / pdf_nee;
+    f3 offset_pos = hit.pos + hit.ffnormal * 0.001f;
+    f3 L = normalize(ls.pos - offset_pos);
+    float dist = distance(ls.pos, offset_pos);
+    float n_dot_l = fmaxn(dot(hit.ffnormal, L), 0.0f);
+    float l_dot_n = fmaxn(dot(-L, ls.normal), 0.0f);
+    if (n_dot_l > 0.0f && l_dot_n > 0.0f) {
+        float t_max = fmaxn(dist * 0.999f, 0.0f);
+        float t_min = VARIANT == 0 ? 0.001f : 0.0001f;
+        f3 f = eval_bsdf(hit.ffnormal, L, wo, m, base_color);
+        float G = (n_dot_l * l_dot_n) / (dist * dist);
+        req.contrib = (xyz(ls.emission) * ls.emission.w * f * G * weight) * throughput;
+        if (VARIANT == 1 && t_min >= t_max) req.add_now = true;      // restir_spatial.wgsl:380-400: "too close" counts as unoccluded, no ray
+        else { req.want = true; req.o = offset_pos; req.d = L; req.tmin = t_min; req.tmax = t_max; }
+    }
+}
+
 // State of a path between two bounce iterations (restir.wgsl:590), after the Russian-roulette test that opens the next iteration:
 // everything the rest of that iteration reads that earlier code wrote. A path can be cut here, parked in HBM (frt_kernels.hip:
 // continuation queue) and resumed by another lane.
@@ -63,9 +105,13 @@ struct LoopState {
 
 // restir.wgsl:460-584 (VARIANT 0) / restir_spatial.wgsl:480-610 (VARIANT 1): the primary hit, read from the G-buffer.
 // Returns with s.alive == false when the path ended here (background, light surface, zero BSDF weight).
+// req != nullptr: the shadow ray of the primary hit's next-event estimate is NOT traced here but handed back (nee_request): the caller adds
+// (req->add_now || (req->want && unoccluded)) ? req->contrib : req->dark to s.accumulated — the only addition path_head makes after it, so the
+// sum has the same operands in the same order, and no ray draws a random number (the collective kernels, frt_kernels.hip: pixel_kernel_wg).
 template <int VARIANT, class Ctx>
-FRT_HD void path_head(Ctx& c, uint32_t pix, uint32_t seed, LoopState& s) {
+FRT_HD void path_head(Ctx& c, uint32_t pix, uint32_t seed, LoopState& s, ShadowReq* req = nullptr) {
     const SceneView& sc = c.sc; const FrameView& fv = c.fv;
+    if (req) { req->want = false; req->add_now = false; req->contrib = splat3(0.0f); req->dark = splat3(0.0f); req->o = splat3(0.0f); req->d = splat3(0.0f); req->tmin = 0.0f; req->tmax = 0.0f; }
     c.rng = seed;
     s.accumulated = splat3(0.0f); s.v1_pos = splat3(0.0f); s.throughput = splat3(1.0f); s.next_dir = splat3(0.0f);
     s.pos = splat3(0.0f); s.ffnormal = splat3(0.0f); s.last_bsdf_pdf = 0.0f;
@@ -123,7 +169,8 @@ FRT_HD void path_head(Ctx& c, uint32_t pix, uint32_t seed, LoopState& s) {
     const bool is_glass = m.transmission > 0.01f;
     bool previous_was_diffuse;
     if (!(is_glass || m.roughness < 0.05f)) {   // :556
-        accumulated = accumulated + nee<VARIANT>(c, hit, wo, m, base_color, throughput);
+        if (req) nee_request<VARIANT>(c, hit, wo, m, base_color, throughput, *req);
+        else accumulated = accumulated + nee<VARIANT>(c, hit, wo, m, base_color, throughput);
         previous_was_diffuse = true;
     } else previous_was_diffuse = false;
 
@@ -231,48 +278,6 @@ FRT_HD void path_loop(Ctx& c, LoopState& s, uint32_t depth_begin, uint32_t depth
     s.pos = hit.pos; s.ffnormal = hit.ffnormal; s.accumulated = accumulated; s.throughput = throughput; s.next_dir = next_dir;
     s.last_bsdf_pdf = last_bsdf_pdf; s.previous_was_diffuse = previous_was_diffuse;
     s.alive = alive;      // still running: the roulette for iteration depth_end has been passed
-}
-
-// ---- one bounce with its two rays pulled apart (the form the stream kernel runs, frt_kernels.hip) -----------------------------
-// path_loop traces the closest-hit ray, shades, traces the shadow ray of the next-event estimate in the middle of the shading, and
-// goes on. Here one iteration is cut at its rays:   [closest-hit ray]  ->  bounce_shade  ->  [shadow ray]  ->  add the estimate
-// bounce_shade does everything else of the iteration — hit, material, emission, light hit, the estimate's value (as if unoccluded), BSDF
-// sample, the next iteration's roulette — and hands back the shadow ray with the value to add when it is unoccluded. Same operations
-// on the same operands as path_loop: the estimate is a pure function of the hit (evaluating it before the visibility test instead of
-// after changes nothing), it is the only addition to `accumulated` between the light-hit test and the end of the iteration, nothing
-// after it reads `accumulated`, and no ray draws a random number, so the rand() sequence is the reference's.
-// dark: what path_loop adds when the estimate is NOT lit — zero, or zero times the throughput (NaN where the throughput is inf / NaN: the
-// reference's GGX term overflows on the roughness-0.01 box, DESIGN.md §3), so that even those paths stay bit-identical.
-struct ShadowReq { bool want; bool add_now; f3 o, d; float tmin, tmax; f3 contrib, dark; };
-
-template <int VARIANT>
-FRT_HD void nee_request(PathCtx& c, const Surf& hit, f3 wo, const MatParams& m, f3 base_color, f3 throughput, ShadowReq& req) {   // nee() + eval_direct_lighting() up to the ray
-    req.want = false; req.add_now = false; req.contrib = splat3(0.0f); req.dark = splat3(0.0f);
-    req.o = splat3(0.0f); req.d = splat3(0.0f); req.tmin = 0.0f; req.tmax = 0.0f;
-    uint32_t nl = c.fv.cam.num_lights;
-    if (nl == 0u) return;
-    uint32_t light_idx = (uint32_t)(c.rand() * (float)nl);
-    if (!(light_idx < nl)) return;
-    req.dark = splat3(0.0f) * throughput;      // from here on nee() returns eval_direct_lighting(...) * throughput
-    LightSmp ls = sample_light(c, light_idx);
-    float pdf_nee = ls.pdf * (1.0f / (float)nl);
-    float p_bsdf = eval_pdf(hit.ffnormal, normalize(ls.pos - hit.pos), wo, m, base_color);
-    float mis_weight_nee = pdf_nee / (pdf_nee + p_bsdf);
-    float weight = mis_weight_nee / pdf_nee;
-    f3 offset_pos = hit.pos + hit.ffnormal * 0.001f;
-    f3 L = normalize(ls.pos - offset_pos);
-    float dist = distance(ls.pos, offset_pos);
-    float n_dot_l = fmaxn(dot(hit.ffnormal, L), 0.0f);
-    float l_dot_n = fmaxn(dot(-L, ls.normal), 0.0f);
-    if (n_dot_l > 0.0f && l_dot_n > 0.0f) {
-        float t_max = fmaxn(dist * 0.999f, 0.0f);
-        float t_min = VARIANT == 0 ? 0.001f : 0.0001f;
-        f3 f = eval_bsdf(hit.ffnormal, L, wo, m, base_color);
-        float G = (n_dot_l * l_dot_n) / (dist * dist);
-        req.contrib = (xyz(ls.emission) * ls.emission.w * f * G * weight) * throughput;
-        if (VARIANT == 1 && t_min >= t_max) req.add_now = true;      // restir_spatial.wgsl:380-400: "too close" counts as unoccluded, no ray
-        else { req.want = true; req.o = offset_pos; req.d = L; req.tmin = t_min; req.tmax = t_max; }
-    }
 }
 
 // Origin of the closest-hit ray of the iteration that starts from state `s` (restir.wgsl:600-605).

@@ -131,7 +131,7 @@ struct frt_renderer {
     uint32_t qparity[2] = {0, 0};
     uint32_t ncuts = 2, cuts[kMaxCuts] = {3, 4, 0, 0};   // measured best on the Cornell Box
     bool vote = false;                     // traced kernels with the voting BVH walk (set from the size of the scene's quad tree, upload_scene)
-    uint32_t walk = kWalkQuad, wide_lds_bytes = 0;      // which tree the traced kernels walk (frt_kernels.hpp: kWalk*; upload_scene)
+    uint32_t walk = kWalkQuad, wide_lds_bytes = 0, wg_rows = 0;      // which tree the traced kernels walk and how (frt_kernels.hpp: kWalk*; upload_scene)
 #if FRT_EXPERIMENTS
     ExpState x;                            // lib/libfrt_exp.so only: state and FRT_* knobs of the measured-and-not-kept kernel designs (csrc/experiments/)
 #endif
@@ -189,10 +189,12 @@ static int upload(frt_renderer* r, const std::vector<T>& v, const D** out) {
 #define FRT_VOTE_MIN_NODES 32768      // (4 MiB of quad nodes; A/B builds: 0 = every scene votes, a huge value = none does)
 #endif
 static const size_t kVoteMinQuadNodes = FRT_VOTE_MIN_NODES;
+#if FRT_EXPERIMENTS
 #ifndef FRT_WIDE_LDS_MAX
 #define FRT_WIDE_LDS_MAX 28672      // bytes of 8-wide nodes a traced workgroup may hold in LDS beside its 9 KiB of stack words: 4 workgroups per CU (A/B builds)
 #endif
 static const size_t kWideLdsMaxBytes = FRT_WIDE_LDS_MAX;
+#endif
 static int upload_scene(frt_renderer* r, const SceneBuilder& b) {
     SceneView& sv = r->sv;
     int rc;
@@ -204,21 +206,30 @@ static int upload_scene(frt_renderer* r, const SceneBuilder& b) {
     // 1.279 / 1.340 ms; 390 (the Cornell Box) 1.565 / 1.611 ms.
     r->vote = b.quad_nodes.size() >= kVoteMinQuadNodes;
     if ((rc = upload(r, b.tri_slots, &sv.tris))) return rc;
-    // The 8-wide tree (frt_bvh8.hpp; frt_trace.hpp: trace8) is walked on request (FRT_FLAG_WALK_WIDE / _HBM) when the scene has one whose stack fits
-    // trace8's kStack8 words. A tree of at most kWideLdsMaxBytes is then copied into every traced workgroup's LDS (kWalkWideLds; the Cornell Box: 174
-    // nodes, 22 KiB; FRT_FLAG_WALK_WIDE_HBM leaves it in HBM). Measured slower than the quad walk on every scene (profiles/r4_experiments/wide8.md):
-    // Cornell Box 1.57 (LDS) / 1.60 (HBM) vs 1.54 ms per frame, ReSTIR scene 1.52 vs 1.27, configs[3] stand-in 3.50 vs 2.99, configs[4] stand-in 26.0 vs 19.6.
     sv.nodes8 = nullptr; sv.tris8 = nullptr; sv.num_nodes8 = 0u; sv.stack_need8 = 0u;
     r->walk = kWalkQuad; r->wide_lds_bytes = 0u;
-    if (b.wide8.ok && b.wide8.stack_need <= (uint32_t)kStack8 && (r->flags & (FRT_FLAG_WALK_WIDE | FRT_FLAG_WALK_WIDE_HBM))) {
-        if ((rc = upload(r, b.wide8.words, &sv.nodes8))) return rc;
-        if ((rc = upload(r, b.tri_slots8, &sv.tris8))) return rc;
-        sv.num_nodes8 = (uint32_t)(b.wide8.words.size() / kWide8Words); sv.stack_need8 = b.wide8.stack_need;
-        const size_t bytes = b.wide8.words.size() * sizeof(uint32_t);
-        r->walk = (bytes <= kWideLdsMaxBytes && !(r->flags & FRT_FLAG_WALK_WIDE_HBM)) ? kWalkWideLds : kWalkWide;
-        r->wide_lds_bytes = r->walk == kWalkWideLds ? (uint32_t)bytes : 0u;
-        r->vote = false;
+    r->wg_rows = b.quad_stack_need + 1u;
+#if FRT_EXPERIMENTS
+    // Round 4's two measured-and-not-kept walks (lib/libfrt_exp.so only; profiles/r4_experiments/wide8.md, collective_walks.md):
+    // FRT_FLAG_WALK_WIDE / _HBM: the 8-wide tree with grid boxes (frt_bvh8.hpp; frt_trace.hpp: trace8) when the scene has one whose stack fits trace8's
+    // kStack8 words; a tree of at most kWideLdsMaxBytes is copied into every traced workgroup's LDS (kWalkWideLds; the Cornell Box: 174 nodes, 22 KiB).
+    // Cornell Box 1.57 (LDS) / 1.60 (HBM) vs 1.54 ms per frame, ReSTIR scene 1.52 vs 1.27, configs[3] stand-in 3.50 vs 2.99, configs[4] stand-in 26.0 vs 19.6.
+    if (r->flags & (FRT_FLAG_WALK_WIDE | FRT_FLAG_WALK_WIDE_HBM)) {
+        b.ensure_wide8();
+        if (b.wide8.ok && b.wide8.stack_need <= (uint32_t)kStack8) {
+            if ((rc = upload(r, b.wide8.words, &sv.nodes8))) return rc;
+            if ((rc = upload(r, b.tri_slots8, &sv.tris8))) return rc;
+            sv.num_nodes8 = (uint32_t)(b.wide8.words.size() / kWide8Words); sv.stack_need8 = b.wide8.stack_need;
+            const size_t bytes = b.wide8.words.size() * sizeof(uint32_t);
+            r->walk = (bytes <= kWideLdsMaxBytes && !(r->flags & FRT_FLAG_WALK_WIDE_HBM)) ? kWalkWideLds : kWalkWide;
+            r->wide_lds_bytes = r->walk == kWalkWideLds ? (uint32_t)bytes : 0u;
+            r->vote = false;
+        }
     }
+    // FRT_FLAG_WG_TRACE: collective walks over the quad tree (frt_kernels.hip: wg_trace): a workgroup's rays re-dealt to dense, direction-sorted waves.
+    // Cornell Box 1.65 (octant-sorted) / 1.55 (dense only) vs 1.43 ms per frame.
+    if (r->walk == kWalkQuad && (r->flags & FRT_FLAG_WG_TRACE)) r->walk = kWalkQuadWg;
+#endif
     if ((rc = upload(r, b.qnode_a, &sv.qnode_a))) return rc;
     if ((rc = upload(r, b.qnode_b, &sv.qnode_b))) return rc;
     for (int a = 0; a < 3; ++a) { sv.qmin[a] = b.qmin[a]; sv.qstep[a] = b.qstep[a]; }
@@ -470,10 +481,10 @@ int frt_scene_get(const frt_scene* s, int which, void* out) {
     case 8: memcpy(out, b.bvh2.data(), b.bvh2.size() * sizeof(frt_bvh2_node)); break;
     case 9: memcpy(out, b.bvh2_tri_index.data(), b.bvh2_tri_index.size() * 4); break;
     case 10: memcpy(out, b.quad_nodes.data(), b.quad_nodes.size() * sizeof(QuadNode)); break;
-    case 11: memcpy(out, b.wide8.words.data(), b.wide8.words.size() * 4); break;
-    case 12: memcpy(out, b.tri_slots8.data(), b.tri_slots8.size() * sizeof(TriSlot)); break;
+    case 11: b.ensure_wide8(); memcpy(out, b.wide8.words.data(), b.wide8.words.size() * 4); break;
+    case 12: b.ensure_wide8(); memcpy(out, b.tri_slots8.data(), b.tri_slots8.size() * sizeof(TriSlot)); break;
     case 13: memcpy(out, b.tri_slots.data(), b.tri_slots.size() * sizeof(TriSlot)); break;
-    case 14: memcpy(out, b.wide8.child_boxes.data(), b.wide8.child_boxes.size() * 4); break;
+    case 14: b.ensure_wide8(); memcpy(out, b.wide8.child_boxes.data(), b.wide8.child_boxes.size() * 4); break;
     default: return fail(FRT_ERR_INVALID_ARG, "get: unknown selector");
     }
     return FRT_OK;
@@ -486,6 +497,7 @@ int frt_scene_bvh_stats(const frt_scene* s, uint32_t st[4]) {
 int frt_scene_tree_stats(const frt_scene* s, uint32_t st[8]) {
     if (!s || !st) return fail(FRT_ERR_INVALID_ARG, "tree_stats: null");
     const SceneBuilder& b = s->b;
+    b.ensure_wide8();
     st[0] = (uint32_t)b.quad_nodes.size(); st[1] = b.quad_stack_need;
     st[2] = b.wide8.ok ? (uint32_t)(b.wide8.words.size() / kWide8Words) : 0u; st[3] = b.wide8.stack_need; st[4] = b.wide8.depth; st[5] = b.wide8.children;
     st[6] = (uint32_t)b.tri_slots8.size(); st[7] = b.quad_fold;
@@ -783,7 +795,10 @@ frt_renderer* frt_renderer_create(const frt_scene* s, uint32_t width, uint32_t h
         r->motion_halo = o->motion_halo_rows;
     }
 #if !FRT_EXPERIMENTS
-    if (r->flags & FRT_FLAG_COMPACTION) { fail(FRT_ERR_INVALID_ARG, "renderer_create: FRT_FLAG_COMPACTION selects an experimental kernel family that lives in lib/libfrt_exp.so (make experiments)"); delete r; return nullptr; }
+    if (r->flags & (FRT_FLAG_COMPACTION | FRT_FLAG_WALK_WIDE | FRT_FLAG_WALK_WIDE_HBM | FRT_FLAG_WG_TRACE)) {
+        fail(FRT_ERR_INVALID_ARG, "renderer_create: FRT_FLAG_COMPACTION / _WALK_WIDE / _WALK_WIDE_HBM / _WG_TRACE select experimental kernel families that live in lib/libfrt_exp.so (make experiments)");
+        delete r; return nullptr;
+    }
 #endif
     if (renderer_init(r, s, o) != FRT_OK) { std::string keep = g_err; frt_renderer_destroy(r); g_err = keep; return nullptr; }
     return r;
@@ -812,7 +827,7 @@ static void trace_launch_of(frt_renderer* r, int stage, bool with_tile_state, Tr
     memset(&L, 0, sizeof(L));
     L.wg_park = true;
     L.vote = r->vote;
-    L.walk = r->walk; L.wide_lds_bytes = r->wide_lds_bytes;
+    L.walk = r->walk; L.wide_lds_bytes = r->wide_lds_bytes; L.wg_rows = r->wg_rows;
     const bool cut = stage_is_cut(r) && r->qcap > 0;
     L.ncuts = cut ? r->ncuts : 0u;
     for (int k = 0; k < kMaxCuts; ++k) L.cuts[k] = r->cuts[k];
@@ -846,7 +861,7 @@ static int launch_g_and_trace(frt_renderer* r, FrameView fv, hipStream_t q, bool
         fv.ray_counters = r->d_counters + (pending ? C_PENDING + 4 * pending_set : C_STAGE);
         frt_renderer::Timed t{};
         if (timed) { int rc = timer_begin(r, t, 0, q); if (rc) return rc; }
-        HIP_TRY(launch_gbuffer(r->sv, fv, q, r->walk));
+        HIP_TRY(launch_gbuffer(r->sv, fv, q, r->walk == kWalkQuadWg ? (uint32_t)kWalkQuad : r->walk));      // (primary rays are coherent: plain walks)
         if (timed) { int rc = timer_end(r, t, q); if (rc) return rc; }
         r->stats.launches[0] += 1;
     }

@@ -115,8 +115,12 @@ public:
     std::vector<uint32_t> qnode_a, qnode_b;     // quantized pair nodes, 4 words per node each (frt_trace.hpp: QBvh)
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};
     std::vector<TriSlot> tri_slots;
-    Wide8 wide8;                            // the same tree as 8-wide compressed nodes (frt_bvh8.hpp; frt_trace.hpp: trace8); wide8.ok = false: not walkable that way
-    std::vector<TriSlot> tri_slots8;        // the triangle slots in the wide tree's order (a node's leaf triangles contiguous)
+    // The same tree as 8-wide nodes with grid boxes (frt_bvh8.hpp; frt_trace.hpp: trace8), built on first use (ensure_wide8): the product's kernels walk
+    // the quad tree; the 8-wide walk is an experiment (lib/libfrt_exp.so) and its tree is otherwise read by tests and tools/bvh_quality.cpp only.
+    mutable Wide8 wide8;                    // wide8.ok = false: not walkable that way (more than 65,536 nodes)
+    mutable std::vector<TriSlot> tri_slots8;   // the triangle slots in the wide tree's order (a node's leaf triangles contiguous)
+    mutable bool wide8_built = false;
+    void ensure_wide8() const;
     std::vector<ShadeTri> shade_tris;
     std::vector<InstanceDev> instances_dev;
     float srgb_lut[256];

@@ -10,7 +10,7 @@ Reference (Rust)                      here
 All arithmetic happens in libfrt.so (HIP); nothing here computes pixels.
 """
 from ._lib import FrtError, lib, Material, Light, VertexAttr, CameraUniform, RenderOpts, Stats  # noqa: F401
-from ._lib import (FLAG_TIMING, FLAG_COMPACTION, FLAG_USE_STREAM, FLAG_OVERLAP_POST, FLAG_PIPELINE, FLAG_THIRD_GSET, FLAG_WALK_WIDE, FLAG_WALK_WIDE_HBM, PHASE_GBUFFER, PHASE_TEMPORAL, PHASE_SPATIAL, PHASE_POST, PHASE_ALL,  # noqa: F401
+from ._lib import (FLAG_TIMING, FLAG_COMPACTION, FLAG_USE_STREAM, FLAG_OVERLAP_POST, FLAG_PIPELINE, FLAG_THIRD_GSET, FLAG_WALK_WIDE, FLAG_WALK_WIDE_HBM, FLAG_WG_TRACE, PHASE_GBUFFER, PHASE_TEMPORAL, PHASE_SPATIAL, PHASE_POST, PHASE_ALL,  # noqa: F401
                    PHASE_SPATIAL_INNER, PHASE_SPATIAL_EDGE, BUF_CANDIDATE,
                    BUF_GPOS, BUF_GNORMAL, BUF_GALBEDO, BUF_GMOTION, BUF_RESERVOIR, BUF_RAW, BUF_DISPLAY, BUF_ACCUM, BUF_BPP)
 from . import geometry, scenes, loader  # noqa: F401

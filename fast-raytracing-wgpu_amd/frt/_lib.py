@@ -54,6 +54,7 @@ FLAG_PIPELINE = 8
 FLAG_THIRD_GSET = 16
 FLAG_WALK_WIDE = 32
 FLAG_WALK_WIDE_HBM = 64
+FLAG_WG_TRACE = 128
 FLAG_OVERLAP_POST = FLAG_PIPELINE      # round-1 name
 PHASE_GBUFFER, PHASE_TEMPORAL, PHASE_SPATIAL, PHASE_POST, PHASE_ALL = 1, 2, 4, 8, 15
 PHASE_SPATIAL_INNER, PHASE_SPATIAL_EDGE = 16, 32

@@ -197,11 +197,14 @@ typedef struct frt_render_opts {
                                        pixel outside the arena) that strip renderers own, so that the next frame's G-buffer + T-trace need not wait
                                        for this frame's T-merge. No gain for a whole frame; lets tests drive that schedule. */
 
-#define FRT_FLAG_WALK_WIDE 32u      /* the traced kernels walk the scene's 8-WIDE tree (csrc/frt_bvh8.hpp, frt_trace.hpp: trace8; a tree of at most 28 KiB is copied into
-                                       every traced workgroup's LDS) instead of the 4-wide one. Same pixels. Built, parity-checked and MEASURED SLOWER in round 4
-                                       (Cornell Box 1.57 vs 1.54 ms per frame, larger scenes 17 - 33 % slower: profiles/r4_experiments/wide8.md), so it is opt-in;
-                                       ignored for a scene whose 8-wide tree needs a deeper stack than trace8 has (8 words) or more than 65,536 nodes */
+/* EXPERIMENTS BUILD ONLY (lib/libfrt_exp.so, `make experiments`; the product library rejects them): round 4's two measured-and-not-kept walks. Same pixels. */
+#define FRT_FLAG_WALK_WIDE 32u      /* the traced kernels walk the scene's 8-WIDE tree with 16-bit grid boxes (csrc/frt_bvh8.hpp, frt_trace.hpp: trace8; a tree of at
+                                       most 28 KiB is copied into every traced workgroup's LDS) instead of the 4-wide one: Cornell Box 1.57 vs 1.54 ms per frame,
+                                       larger scenes 17 - 33 % slower (profiles/r4_experiments/wide8.md) */
 #define FRT_FLAG_WALK_WIDE_HBM 64u  /* the same walk with the tree read from HBM / L1 even when it would fit a workgroup's LDS */
+#define FRT_FLAG_WG_TRACE 128u      /* the traced kernels walk their rays COLLECTIVELY: before every walk a 16x16 workgroup re-deals its rays to dense waves sorted by
+                                       direction octant through LDS (csrc/experiments/frt_round4_walks.hpp: wg_trace): 1.65 vs 1.43 ms per frame
+                                       (profiles/r4_experiments/collective_walks.md) */
 
 /* FRT_PHASE_SPATIAL = the whole spatial stage. A strip renderer may issue it in two parts so that the halo exchange overlaps with
  * work: FRT_PHASE_SPATIAL_INNER (rows whose 10-row reuse neighbourhood lies inside the strip: needs nothing from a neighbour),

@@ -58,8 +58,17 @@ static void run_stage_cut(HostCheck* h, FrameView& fv, uint32_t cut, unsigned lo
             seed = r.y;
         }
         LoopState s;
-        path_head<V>(c, pix, seed, s);
-        if (s.alive) path_loop<V>(c, s, 1u, cut < fv.max_depth ? cut : fv.max_depth);
+        if (pulled_apart) {      // the form the collective kernels run (frt_kernels.hip: pixel_kernel_wg): the head's shadow ray handed back, then pulled-apart bounces
+            ShadowReq req;
+            path_head<V>(c, pix, seed, s, &req);
+            bool lit = req.add_now;
+            if (req.want) lit = !c.any(req.o, req.d, req.tmin, req.tmax);
+            s.accumulated = s.accumulated + (lit ? req.contrib : req.dark);
+            if (s.alive) path_loop_split<V>(c, s, 1u, cut < fv.max_depth ? cut : fv.max_depth);
+        } else {
+            path_head<V>(c, pix, seed, s);
+            if (s.alive) path_loop<V>(c, s, 1u, cut < fv.max_depth ? cut : fv.max_depth);
+        }
         rc[0] += c.n_closest; rc[1] += c.n_any;
         if (s.alive) cont_store(qa, ca++, pix, c.rng, true, s, STAGE == 2 ? &r : nullptr);
         else finish_on_host<STAGE>(c, fv, pix, r, s, split);
@@ -97,6 +106,7 @@ void* hc_create(const frt_scene* s, uint32_t W, uint32_t H, uint32_t max_depth, 
     sv.nodes = reinterpret_cast<const float4*>(b.pair_nodes.data());
     sv.nodes4 = reinterpret_cast<const float4*>(b.quad_nodes.data());
     sv.tris = reinterpret_cast<const float4*>(b.tri_slots.data());
+    b.ensure_wide8();
     sv.nodes8 = b.wide8.ok ? reinterpret_cast<const uint4*>(b.wide8.words.data()) : nullptr;
     sv.tris8 = reinterpret_cast<const float4*>(b.tri_slots8.data());
     sv.num_nodes8 = b.wide8.ok ? (uint32_t)(b.wide8.words.size() / kWide8Words) : 0u; sv.stack_need8 = b.wide8.stack_need;
@@ -198,6 +208,7 @@ void hc_trace(const frt_scene* s, int any, uint32_t n, const float* o, const flo
     sv.nodes = reinterpret_cast<const float4*>(b.pair_nodes.data());
     sv.nodes4 = reinterpret_cast<const float4*>(b.quad_nodes.data());
     sv.tris = reinterpret_cast<const float4*>(b.tri_slots.data());
+    b.ensure_wide8();
     sv.nodes8 = b.wide8.ok ? reinterpret_cast<const uint4*>(b.wide8.words.data()) : nullptr;
     sv.tris8 = reinterpret_cast<const float4*>(b.tri_slots8.data());
     sv.num_nodes8 = b.wide8.ok ? (uint32_t)(b.wide8.words.size() / kWide8Words) : 0u; sv.stack_need8 = b.wide8.stack_need;
@@ -253,6 +264,7 @@ void hc_quad_stats(const frt_scene* s, uint32_t out[6]) {
 // inner children hit, leaf children reached, triangle slots covered by them, children per node x 100, grid boxes that do not contain their child's float box, levels}
 void hc_wide8_stats(const frt_scene* s, uint32_t out[8]) {
     const SceneBuilder& b = s->b;
+    b.ensure_wide8();
     for (int i = 0; i < 8; ++i) out[i] = 0;
     if (!b.wide8.ok) return;
     const std::vector<uint32_t>& w = b.wide8.words;

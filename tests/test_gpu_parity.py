@@ -51,50 +51,6 @@ def test_kernels_match_oracle_every_buffer(gpu, orc, which, W, H, depth, frames)
     assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])      # device ray counters are exact
 
 
-@pytest.mark.parametrize("which,W,H,depth,frames,flag", [("cornell", 128, 128, 8, 4, "WIDE"), ("cornell", 96, 64, 16, 3, "WIDE_HBM"), ("cornell", 37, 19, 8, 3, "WIDE"),
-                                                         ("restir", 160, 96, 8, 3, "WIDE"), ("blob5k", 64, 48, 8, 2, "WIDE")])
-def test_wide_walk_matches_oracle_every_buffer(gpu, orc, which, W, H, depth, frames, flag):
-    """The opt-in walk over the 8-wide tree with 16-bit grid boxes (FRT_FLAG_WALK_WIDE: csrc/frt_bvh8.hpp, frt_trace.hpp: trace8 — hit-mask stack words,
-    octant order, nearest-first for any-hit rays; the Cornell Box's tree in every traced workgroup's LDS, larger trees and _HBM from memory): every buffer
-    of every frame and the exact ray counts against the oracle, which walks the binary tree (blob5k: brute force, nothing of the product's)."""
-    frt = gpu
-    import _scenes
-    if which == "blob5k":
-        fs, os_ = _scenes.bumpy_sphere_in_box(frt, orc, subdiv=4, share_bvh=False)
-    else:
-        fs = frt.scenes.create_cornell_box() if which == "cornell" else frt.scenes.create_restir_scene()
-        os_ = orc.cornell() if which == "cornell" else orc.restir_scene()
-        os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
-    t = fs.tree_stats()
-    assert 0 < t["wide8_nodes"] and t["wide8_stack_need"] <= 8
-    r = frt.Renderer(fs, W, H, max_depth=depth, flags=frt.FLAG_PIPELINE | getattr(frt, "FLAG_WALK_" + flag))
-    ro = os_.renderer(W, H, depth, which != "blob5k", 16)
-    for f in range(frames):
-        cam = frt.CameraController().build_uniform(W / H, f, fs.num_lights)
-        r.render(cam); ro.render(cam)
-        compare_all(r.read_buffer, ro.read, f, f"{which} {W}x{H} depth {depth}, 8-wide walk ({flag})")
-    st, so = r.stats(), ro.stats()["total"]
-    assert (st["rays_closest"], st["rays_any"]) == (so["closest"], so["any"])
-
-
-def test_wide_walk_equals_quad_walk_at_full_size(gpu):
-    """1920x1080, MAX_DEPTH 8, 4 frames: the three walks (quad tree; 8-wide tree in LDS; 8-wide tree from HBM) give the same image bit for bit and the
-    same ray counts — hits do not depend on the tree (frt_trace.hpp)."""
-    frt = gpu
-    W, H, N = 1920, 1080, 4
-    fs = frt.scenes.create_cornell_box()
-    cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(N)]
-    out = []
-    for extra in (0, frt.FLAG_WALK_WIDE, frt.FLAG_WALK_WIDE_HBM):
-        r = frt.Renderer(fs, W, H, flags=frt.FLAG_PIPELINE | extra)
-        for c in cams: r.render(c)
-        st = r.stats()
-        out.append((r.read_accum(), r.read_buffer(frt.BUF_RESERVOIR, 1), st["rays_closest"], st["rays_any"]))
-        del r
-    for o in out[1:]:
-        assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1]) and o[2:] == out[0][2:]
-
-
 @pytest.mark.parametrize("which,W,H,depth,frames", [("cornell", 128, 128, 8, 3), ("blob5k", 64, 48, 8, 2)])
 def test_kernels_match_the_brute_force_oracle(gpu, orc, which, W, H, depth, frames):
     """The one comparison in which NO product data feeds the checker (parity caveat): the oracle is never handed the product's BVH —

@@ -24,12 +24,10 @@ def test_bumpy_sphere_scene_host_parity(frt, orc, hostcheck):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["bumpy82k", "colonnade250k", "bumpy82k-wide", "colonnade250k-wide"])
+@pytest.mark.parametrize("which", ["bumpy82k", "colonnade250k"])
 def test_mesh_scenes_on_gpu(frt, orc, which):
     if frt.lib().frt_device_count() < 1:
         pytest.fail("no HIP device")
-    wide = which.endswith("-wide")          # the opt-in walk over the 8-wide tree (FRT_FLAG_WALK_WIDE), read from HBM at these sizes
-    which = which.replace("-wide", "")
     if which == "bumpy82k":
         fs, os_ = _scenes.bumpy_sphere_in_box(frt, orc, subdiv=6)     # configs[3]: ~82k triangles, 8 bounces
         depth, W, H, frames = 8, 160, 90, 3
@@ -39,10 +37,7 @@ def test_mesh_scenes_on_gpu(frt, orc, which):
         depth, W, H, frames = 16, 160, 90, 2
         assert fs.counts()["tris"] > 245000
     assert fs.bvh_stats()["depth"] <= 30
-    if wide:
-        t = fs.tree_stats()
-        assert 0 < t["wide8_nodes"] <= 65536 and t["wide8_stack_need"] <= 8, t
-    r = frt.Renderer(fs, W, H, max_depth=depth, flags=frt.FLAG_WALK_WIDE if wide else 0)
+    r = frt.Renderer(fs, W, H, max_depth=depth)
     ro = os_.renderer(W, H, depth, True, 16)
     for f in range(frames):
         cam = frt.CameraController().build_uniform(W / H, f, fs.num_lights)

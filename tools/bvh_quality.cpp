@@ -544,6 +544,7 @@ int main(int argc, char** argv) {
     g_leafloop = argc > 10 ? atoi(argv[10]) : 0;
     g_unified = argc > 11 ? atoi(argv[11]) : 0;
     g_precise = argc > 12 ? atoi(argv[12]) : 0;
+    const int sort256 = argc > 13 ? atoi(argv[13]) : 0;
     // the 8-wide compressed tree as the product built it (csrc/frt_bvh8.hpp), decoded from its device form
     WideTree WT;
     {
@@ -589,6 +590,61 @@ int main(int argc, char** argv) {
     // benchmark camera: (0, 0, 3) looking down -z, 45 degrees vertical, 16:9 (camera.rs:40-42, :218-222)
     const int W = 1920, H = 1080;
     const float th = std::tan(0.5f * 45.0f * 3.14159265f / 180.0f), aspect = (float)W / H;
+
+    // Experiment (argument 13): would re-dealing a 16x16 workgroup's bounce rays to its four waves by direction pay? Blocks of 2x2 tiles; the 256
+    // bounce rays of a block walked (a) tile by tile, as the kernels do, (b) sorted by direction octant (1) or by octant + origin cell (2) and cut into
+    // four waves. Reports wave-level node + leaf steps of both.
+    if (sort256) {
+        WaveCost byTile, sorted;
+        std::vector<Lane> B(256), Wv(64);
+        std::vector<char> bact(256), wact(64);
+        for (int blk = 0; blk < tiles / 4; ++blk) {
+            int bx = (int)(rnd() * (W / 16)), by = (int)(rnd() * (H / 16));
+            V3 eye{0, 0, 3};
+            for (int q = 0; q < 4; ++q) {
+                for (int i = 0; i < 64; ++i) {
+                    float px = bx * 16 + (q & 1) * 8 + (i & 7) + 0.5f, py = by * 16 + (q >> 1) * 8 + (i >> 3) + 0.5f;
+                    float nx = px / W * 2 - 1, ny = 1 - py / H * 2;
+                    Wv[i].start(eye, norm({nx * th * aspect, ny * th, -1}), 0.001f, 1000.0f, false); wact[i] = 1;
+                }
+                WaveCost dummy; run_wave(T, Wv, wact, dummy);
+                for (int i = 0; i < 64; ++i) {
+                    const int k = q * 64 + i;
+                    bact[k] = Wv[i].hit != kNone && rnd() <= g_presence;      // (presence: the share of lanes that bring a ray to this walk)
+                    if (!bact[k]) continue;
+                    const Tri& t = T.tris[Wv[i].hit];
+                    V3 n = norm(cross(t.e1, t.e2));
+                    if (dot(n, Wv[i].d) > 0) n = n * -1.0f;
+                    V3 pp = Wv[i].o + Wv[i].d * Wv[i].best;
+                    B[k].start(pp + n * 0.001f, cosine_dir(n), 0.001f, 100.0f, false);
+                }
+            }
+            for (int q = 0; q < 4; ++q) {      // (a) tile by tile
+                for (int i = 0; i < 64; ++i) { wact[i] = bact[q * 64 + i]; if (wact[i]) Wv[i].start(B[q * 64 + i].o, B[q * 64 + i].d, 0.001f, 100.0f, false); }
+                run_wave(T, Wv, wact, byTile);
+            }
+            std::vector<int> idx;
+            for (int k = 0; k < 256; ++k) if (bact[k]) idx.push_back(k);
+            auto key = [&](int k) {
+                const V3 d = B[k].d;
+                uint32_t oct = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+                uint32_t sub = 0;
+                if (sort256 >= 2) { const float ax = std::fabs(d.x), ay = std::fabs(d.y), az = std::fabs(d.z); sub = ax > ay ? (ax > az ? 0u : 2u) : (ay > az ? 1u : 2u); }
+                return oct * 4u + sub;
+            };
+            if (sort256 != 3) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(a) < key(b); });      // (3: dense waves, arrival order)
+            for (size_t w0 = 0; w0 < idx.size(); w0 += 64) {      // (b) dense waves of the sorted rays
+                for (int i = 0; i < 64; ++i) { wact[i] = w0 + i < idx.size(); if (wact[i]) { const Lane& r = B[idx[w0 + i]]; Wv[i].start(r.o, r.d, 0.001f, 100.0f, false); } }
+                run_wave(T, Wv, wact, sorted);
+            }
+        }
+        printf("bounce rays of 16x16 blocks, walked tile by tile vs re-dealt to dense waves by direction (%s):\n", sort256 >= 2 ? "octant + major axis" : "octant");
+        report("by tile", byTile); report("sorted", sorted);
+        printf("  total wave steps: by tile %llu node + %llu leaf in %llu waves; sorted %llu + %llu in %llu waves; checksum %llu %llu\n", (unsigned long long)byTile.wave_nodes, (unsigned long long)byTile.wave_leaves,
+               (unsigned long long)byTile.wave_rays, (unsigned long long)sorted.wave_nodes, (unsigned long long)sorted.wave_leaves, (unsigned long long)sorted.wave_rays, (unsigned long long)byTile.checksum, (unsigned long long)sorted.checksum);
+        frt_scene_destroy(s);
+        return 0;
+    }
     WaveCost primary, bounce1, shadow, bounce2, chained;
     std::vector<Lane> L(64);
     std::vector<char> act(64), act2(64);
