@@ -201,7 +201,16 @@ int strip_step(frt_multi_renderer* m, size_t k, int step) {
         return FRT_OK;
     };
     int rc;
+    // rows a gather may still be copying (frt_multi_renderer_gather with a caller's stream): this frame's first writers wait for the copy
+    auto wait_gather = [&]() -> int {
+        if (!s.gather_pending) return FRT_OK;
+        HIPM_TRY(hipStreamWaitEvent(q, s.ev_gather, 0));
+        if (qe != q) HIPM_TRY(hipStreamWaitEvent(qe, s.ev_gather, 0));
+        s.gather_pending = false;
+        return FRT_OK;
+    };
     if (step == 0) {
+        if ((rc = wait_gather())) return rc;      // (T-merge rewrites the temporal reservoirs)
         if (prev_post) {
             rc = exchange_into(m, k, POST, FRT_BUF_ACCUM, (int)((m->frame - 1u) & 1u), K ? K + kHaloHistory : kHaloHistory);      // a whole frame of slack
             if (rc) return rc;
@@ -226,11 +235,7 @@ int strip_step(frt_multi_renderer* m, size_t k, int step) {
         if ((rc = wait_neighbours(q, &Strip::ev_copy_pre))) return rc;
         if (qe != q && (rc = wait_neighbours(qe, &Strip::ev_copy_pre))) return rc;
     }
-    if (s.gather_pending) {      // ... and raw / reservoirs / display rows a gather may still be copying
-        HIPM_TRY(hipStreamWaitEvent(q, s.ev_gather, 0));
-        if (qe != q) HIPM_TRY(hipStreamWaitEvent(qe, s.ev_gather, 0));
-        s.gather_pending = false;
-    }
+    if ((rc = wait_gather())) return rc;      // ... and raw / spatial reservoirs / display rows a gather may still be copying
     rc = frt_renderer_render_phases(s.r, cam, FRT_PHASE_SPATIAL_INNER);       // interior rows: need nothing from a neighbour
     if (rc) return rc;
     HIPM_TRY(hipStreamWaitEvent(qe, s.ev_copy_mid, 0));      // the edge rows' stream waits for the neighbours' reservoirs
