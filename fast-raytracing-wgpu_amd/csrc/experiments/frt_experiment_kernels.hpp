@@ -1,5 +1,5 @@
 // frt_experiment_kernels.hpp — kernel designs that were built, checked bit for bit against the oracle, measured and NOT kept as the default
-// ("What was tried"; numbers in profiles/r2_experiments/). They are compiled only into lib/libfrt_exp.so
+// (HISTORY.md section 6, "What was tried"; numbers in profiles/r2_experiments/). They are compiled only into lib/libfrt_exp.so
 // (`make experiments`: -DFRT_EXPERIMENTS=1), which the sweep scripts under tools/ and tests/test_experiments.py load; the product library
 // lib/libfrt.so contains none of this code and reads none of its environment knobs.
 //   compact_kernel            FRT_FLAG_COMPACTION   workgroup-level path compaction over the resumable state machine of frt_path.hpp
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(kBlock, 4) stream_kernel(SceneView sc, FrameVi
 }
 
 // ---- ray-level wavefront (opt-in, FRT_WAVEFRONT=1) -----------------------------------------------------------------------------------
-// What the experiments above point to: the traced kernels lose their lanes to wave-level TRAVERSAL divergence, so traversal
+// What the experiments above point to (HISTORY.md §6): the traced kernels lose their lanes to wave-level TRAVERSAL divergence, so traversal
 // gets a kernel of its own. After the pixel kernel (primary hit only, cut at depth 1) each bounce depth d is two launches:
 //   wf_trace_kernel   persistent waves take RAYS — the closest-hit ray of a parked path's iteration d, or the shadow ray its iteration d-1
 //                     left pending — from an item list, one ray per lane, and a lane that finishes its ray takes the next one (resumable

@@ -1,4 +1,4 @@
-"""The kernel designs that were measured and not kept (csrc/experiments/) live in lib/libfrt_exp.so, outside the
+"""The kernel designs that were measured and not kept (csrc/experiments/, HISTORY.md section 6; round 4: profiles/r4_experiments) live in lib/libfrt_exp.so, outside the
 product library. They stay correct: each family renders the Cornell Box bit for bit like the oracle. The PRODUCT library ignores their
 environment knobs and rejects FRT_FLAG_COMPACTION."""
 import json

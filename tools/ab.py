@@ -1,6 +1,6 @@
 """A/B timing of renderer variants in ONE process (interleaved rounds, §5.4 rule 24 of the CDNA guide) at 1920x1080.
 Edit `rs` to compare flags (frt.FLAG_COMPACTION, frt.FLAG_OVERLAP_POST) or environment knobs (FRT_CUTS, FRT_BVH_LEAF) set before
-a Renderer / scene is created. The sweeps quoted in DESIGN.md §6 were produced with this script."""
+a Renderer / scene is created. The sweeps quoted in HISTORY.md §6 were produced with this script."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fast-raytracing-wgpu_amd"))
