@@ -7,7 +7,7 @@ Two kinds of case, drawn at random:
   A  one renderer vs the oracle: every buffer of every frame bit for bit (tests/test_hostcheck_parity.py::compare_all) + the exact ray counters;
      scene (Cornell Box / ReSTIR scene / 5k-triangle blob with the brute-force oracle), W x H (ragged tiles included), MAX_DEPTH, flags
      (plain / two streams / three G-buffer sets), continuation-queue capacity (tiny ones overflow: paths finish in place), cut depths, camera
-     (static, moving with random steps, starts and stops, frame counter restarted while it moves as state.rs:152 does).
+     (static, moving with random steps, starts and stops, frame counter restarted while it moves as state.rs:152 does, Halton-jittered).
   B  strips vs the whole image: frt_multi_renderer (every strip on device 0: peer copies become device copies, the orderings are the real ones) and
      host-exchanged strip renderers against one renderer, static and moving camera (motion halo), bit for bit + ray totals.
 Every failure prints the case's parameters (re-run it alone with --seed S --only K). Exit code = number of failing cases."""
@@ -70,16 +70,28 @@ def case_a(rng, orc, k):
         fs, os_ = _scenes.bumpy_sphere_in_box(frt, orc, subdiv=4, share_bvh=False)
     if not brute:
         os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
-    cams, restarts, cdesc = camera_sequence(rng, W / H, fs.num_lights, frames)
-    desc += " camera " + cdesc
+    jscale = float(rng.choice([1.0, 5.0, 23.0])) if rng.random() < 0.12 else 0.0
     r = frt.Renderer(fs, W, H, max_depth=depth, flags=flags, queue_capacity=qcap, cuts=cuts)
     ro = os_.renderer(W, H, depth, not brute, 16)
+    if jscale:       # the jitter plumbing the reference multiplies by zero (camera.rs:202-203): sheared projection, bilinear post taps
+        ctl, cams, restarts, jits = frt.CameraController(), [], set(), []
+        for f in range(frames):
+            jits.append(ctl.get_halton_jitter(f, W, H, jscale))
+            cams.append(ctl.build_uniform(W / H, f, fs.num_lights, jits[-1])); ctl.commit_frame()
+        desc += f" camera jittered x{jscale}"
+    else:
+        cams, restarts, cdesc = camera_sequence(rng, W / H, fs.num_lights, frames)
+        jits = None
+        desc += " camera " + cdesc
     for f, cam in enumerate(cams):
         if f in restarts:
             r.reset(); ro.restart_counter()
         if restarts:
             cam.frame_count = r.frame_count
-        r.render(cam); ro.render(cam)
+        if jits:
+            ro.set_jitter(jits[f]); ro.render(cam); r.render(cam, jitter=jits[f])
+        else:
+            r.render(cam); ro.render(cam)
         compare_all(r.read_buffer, ro.read, f, desc)
         assert r.frame_count == ro.frame_count, desc
     st, so = r.stats(), ro.stats()["total"]
