@@ -5,7 +5,7 @@ capacities and camera sequences nobody picked by hand. Test infrastructure (the 
 
 Two kinds of case, drawn at random:
   A  one renderer vs the oracle: every buffer of every frame bit for bit (tests/test_hostcheck_parity.py::compare_all) + the exact ray counters;
-     scene (Cornell Box / ReSTIR scene / 5k-triangle blob with the brute-force oracle), W x H (ragged tiles included), MAX_DEPTH, flags
+     scene (Cornell Box / ReSTIR scene / 5k-triangle blob with the brute-force oracle / tests/_scenes.py::random_scene), W x H (ragged tiles included), MAX_DEPTH, flags
      (plain / two streams / three G-buffer sets), continuation-queue capacity (tiny ones overflow: paths finish in place), cut depths, camera
      (static, moving with random steps, starts and stops, frame counter restarted while it moves as state.rs:152 does, Halton-jittered).
   B  strips vs the whole image: frt_multi_renderer (every strip on device 0: peer copies become device copies, the orderings are the real ones) and
@@ -51,8 +51,8 @@ def camera_sequence(rng, aspect, nl, frames):
 
 
 def case_a(rng, orc, k):
-    which = rng.choice(["cornell", "restir", "blob"], p=[0.6, 0.25, 0.15])
-    brute = which == "blob" or rng.random() < 0.1
+    which = rng.choice(["cornell", "restir", "blob", "random"], p=[0.4, 0.2, 0.1, 0.3])
+    brute = which == "blob" or (which != "random" and rng.random() < 0.1)
     W, H = int(rng.integers(8, 300)), int(rng.integers(8, 200))
     if brute:
         W, H = min(W, 96), min(H, 64)
@@ -66,9 +66,13 @@ def case_a(rng, orc, k):
         fs, os_ = frt.scenes.create_cornell_box(), orc.cornell()
     elif which == "restir":
         fs, os_ = frt.scenes.create_restir_scene(), orc.restir_scene()
+    elif which == "random":      # a room of randomly placed / rotated / mirrored shapes in random diffuse, glossy, metal, glass, textured materials, 1 - 3 lights
+        sseed = int(rng.integers(9, 10 ** 6))
+        fs, os_, _ = _scenes.random_scene(frt, orc, sseed)
+        desc += f" scene seed {sseed}"
     else:
         fs, os_ = _scenes.bumpy_sphere_in_box(frt, orc, subdiv=4, share_bvh=False)
-    if not brute:
+    if not brute and which != "random":
         os_.set_bvh(fs.get("bvh2_nodes"), fs.get("bvh2_tri_index"))
     jscale = float(rng.choice([1.0, 5.0, 23.0])) if rng.random() < 0.12 else 0.0
     r = frt.Renderer(fs, W, H, max_depth=depth, flags=flags, queue_capacity=qcap, cuts=cuts)
