@@ -422,9 +422,19 @@ def main():
         off = (-arena.data_ptr()) % 256
         # Same instrumentation at every N: the two-stream schedule, NO per-stage events inside the timed region (two event records per stage and
         # frame cost a thin strip 0.04 of its 0.43 ms); the per-stage times of the JSON line come from a short instrumented pass afterwards.
-        r = frt.Renderer(scene, width, height, max_depth=MAX_DEPTH, device=local_rank, stream=stream.cuda_stream,
-                         rows=(pl.row_begin, pl.row_end) if world > 1 else None,
-                         arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_PIPELINE)
+        if world == 1:
+            r = frt.Renderer(scene, width, height, max_depth=MAX_DEPTH, device=local_rank, stream=stream.cuda_stream,
+                             arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_PIPELINE)
+        else:
+            # A strip renderer under the pipeline enqueues on FOUR streams (main, ahead, two edge streams) and the HIP runtime has four hardware queues per
+            # process (GPU_MAX_HW_QUEUES): created one after the other they get a queue each. Handed torch's current stream as its main stream — created
+            # long before, with torch's and RCCL's own streams in between — the main and the ahead stream landed on ONE queue and the two-stream schedule
+            # ran in series: 0.56 instead of 0.34 ms per frame for a 1/8 strip (tools/rccl_strip_time.py, profiles/r4_experiments/rccl_strips.md).
+            # So the renderer creates its main stream itself and torch (the RCCL transfers of frt.dist) is told to order its work on that stream.
+            torch.cuda.synchronize()           # (the arena was zeroed on torch's current stream)
+            r = frt.Renderer(scene, width, height, max_depth=MAX_DEPTH, device=local_rank, rows=(pl.row_begin, pl.row_end),
+                             arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_PIPELINE)
+            torch.cuda.set_stream(torch.cuda.ExternalStream(r.stream_handle(0), device=f"cuda:{local_rank}"))
         return r, ArenaRows(r, arena, staging_device=None if a.backend == "nccl" else "cpu")
 
     r, rows = make(W, H, plan)
@@ -504,6 +514,8 @@ def main():
     # configs[2]: the same scene at 3840x2160, the workload BASELINE.json tiles over 8 GPUs (extra key; the headline stays configs[1])
     extra4k = None
     if not a.no_4k:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())      # (the strip renderer's main stream goes away with the renderer)
         del r, rows, frame
         torch.cuda.empty_cache()
         plan4 = StripPlan(H4K, world, rank, [b * 2 for b in bounds] if bounds else None)
@@ -515,6 +527,8 @@ def main():
         extra4k = {"workload": "Cornell Box 3840x2160, MAX_DEPTH 8 (BASELINE.json configs[2])", "value": rays4 / el4 / 1e6, "unit": "Mrays/s",
                    "ms_per_step": el4 / k4 * 1e3, "steps": k4, "warmup": w4, "rays_per_frame": rays4 / k4,
                    "rows": [plan4.row_begin, plan4.row_end] if world == 1 else plan4.boundaries}
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
         del r4, rows4
 
     if rank == 0:

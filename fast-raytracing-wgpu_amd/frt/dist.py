@@ -143,7 +143,9 @@ def start_exchange(access, plan, frame, group=None, when="mid", serial=None):
     With the nccl backend the transfer is ordered behind the torch stream that is current HERE and finish() orders the stream that is
     current THERE behind it: callers pick the streams (render_strip_frame)."""
     import torch.distributed as dist
-    tr = plan.transfers(frame, when, serial) if serial is not None else plan.transfers(frame, when)
+    tr = []
+    for w in ((when,) if isinstance(when, str) else when):      # several exchanges in ONE batch (one RCCL launch instead of one each)
+        tr += plan.transfers(frame, w, serial) if serial is not None else plan.transfers(frame, w)
     if not tr:
         return None
     ops, recvs = [], []
@@ -166,24 +168,24 @@ def render_strip_frame(r, access, plan, cam, frame, frt, group=None, serial=None
     """One frame of one rank's strip renderer `r` (frt.Renderer on torch's current stream, buffers in `access`'s arena).
 
     Everything a transfer touches (reservoirs, accumulation) is produced on the renderer's main stream = torch's current stream, so the
-    transfers are ordered by that stream alone. The "post" rows (previous accumulation) are posted first: they have the whole frame to
-    arrive. The "mid" rows are posted behind T-merge and overlap the interior rows of the spatial stage; only its edge rows wait.
+    transfers are ordered by that stream alone. ONE batch per frame (static camera): the "mid" rows (this frame's temporal reservoirs) and
+    the "post" rows (the previous frame's accumulation, needed only by this frame's post stage) are posted together behind T-merge and
+    overlap the interior rows of the spatial stage; only its edge rows wait. (Two batches — "post" at the start of the frame, "mid" behind
+    T-merge — put two RCCL launches with ~50 us of launch latency each on a thin strip's chain: 0.503 -> 0.43 ms per frame for a 1/8 strip
+    of the 1080p frame, tools/rccl_strip_time.py.)
     With a host-staged transport (gloo rehearsal, `access.staging`) start_exchange blocks in the device-to-host copy; same order."""
-    post = start_exchange(access, plan, frame, group, when="post")      # behind post(f-1)
     pre = start_exchange(access, plan, frame, group, when="pre", serial=serial)        # behind spatial(f-1) (moving camera only)
     if pre:
         pre.finish()
     r.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)        # T-merge(f) (G-buffer + T-trace ran ahead of the frame)
-    mid = start_exchange(access, plan, frame, group, when="mid")        # behind T-merge(f)
+    mid = start_exchange(access, plan, frame, group, when=("mid", "post"))      # behind T-merge(f) — and so behind post(f-1)
     r.render_phases(cam, frt.PHASE_SPATIAL_INNER)                       # interior rows: need nothing from a neighbour
     if mid:
         import torch
         with torch.cuda.stream(access.edge_stream()):
-            mid.finish()                                                # only the stream of the edge rows waits for the neighbours' reservoirs
-    r.render_phases(cam, frt.PHASE_SPATIAL_EDGE)                        # edge rows (beside the interior ones) + continuations
-    if post:
-        post.finish()
-    r.render_phases(cam, frt.PHASE_POST)
+            mid.finish()                                                # only the stream of the edge rows waits for the neighbours' rows
+    r.render_phases(cam, frt.PHASE_SPATIAL_EDGE)                        # edge rows (beside the interior ones) + continuations: the main stream joins the edge stream
+    r.render_phases(cam, frt.PHASE_POST)                                # ... and is thereby behind the arrival of the accumulation rows
     r.end_frame()
 
 

@@ -1,0 +1,69 @@
+"""What the RCCL halo exchanges cost a thin strip, measured on ONE GPU: the N > 1 frame loop of bench.py (frt.dist.render_strip_frame) for strip 4 of 8 of the
+1080p frame over the real "nccl" backend with a world of one rank — every transfer a send-to-self of the rows a neighbour would send (same bytes, same
+stream orderings; tests/_nccl_selftest.py checks the pixels of this set-up) — against the same loop without transfers. The HIP runtime maps a process's
+streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): a strip renderer under the pipeline uses four streams itself, RCCL adds its own.
+    [GPU_MAX_HW_QUEUES=8] [RCCL_STRIP_TORCH_STREAM=1 [RCCL_STRIP_OWN_STREAM=1]] python tools/rccl_strip_time.py [rank world]
+RCCL_STRIP_TORCH_STREAM=1: the renderer is handed torch's current stream as its main stream (what bench.py did before round 4's fix)."""
+import os, sys, time
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fast-raytracing-wgpu_amd"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29577"), RANK="0", WORLD_SIZE="1")
+import torch
+import torch.distributed as dist
+import frt
+from frt.dist import StripPlan, ArenaRows, render_strip_frame, HALO_RESERVOIR, BUF_RESERVOIR, BUF_ACCUM
+rank = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+W, H = 1920, 1080
+rb, re = H * rank // world, H * (rank + 1) // world
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+
+class Loopback(StripPlan):
+    def __init__(self, quiet):
+        self.H, self.world, self.rank, self.motion_halo = H, 1, 0, 0
+        self.boundaries = [0, H]; self.row_begin, self.row_end = rb, re
+        self.quiet = quiet
+
+    def transfers(self, frame, when="mid"):
+        if self.quiet:
+            return []
+        if when == "mid":      # both neighbours: 12 rows each way
+            return [(0, BUF_RESERVOIR, 0, (rb, rb + HALO_RESERVOIR), (re, re + HALO_RESERVOIR)), (0, BUF_RESERVOIR, 0, (re - HALO_RESERVOIR, re), (rb - HALO_RESERVOIR, rb))]
+        if when == "post" and frame > 0:
+            return [(0, BUF_ACCUM, (frame - 1) % 2, (rb, rb + 1), (re, re + 1)), (0, BUF_ACCUM, (frame - 1) % 2, (re - 1, re), (rb - 1, rb))]
+        return []
+
+
+if os.environ.get("RCCL_STRIP_OWN_STREAM"):      # main stream = a stream of torch's pool instead of the legacy default stream
+    torch.cuda.set_stream(torch.cuda.Stream())
+scene = frt.scenes.create_cornell_box()
+nbytes = frt.Renderer.arena_bytes(W, H)
+arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device="cuda:0")
+off = (-arena.data_ptr()) % 256
+if not os.environ.get("RCCL_STRIP_TORCH_STREAM"):      # (bench.py since round 4) the renderer creates its main stream itself, next to its other streams; torch is told to use it
+    torch.cuda.synchronize()
+    r = frt.Renderer(scene, W, H, device=0, rows=(rb, re), arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_PIPELINE)
+    torch.cuda.set_stream(torch.cuda.ExternalStream(r.stream_handle(0)))
+else:
+    r = frt.Renderer(scene, W, H, device=0, stream=torch.cuda.current_stream().cuda_stream, rows=(rb, re), arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_PIPELINE)
+rows = ArenaRows(r, arena)
+cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(80)]
+res, host = {}, {}
+for rnd in range(1 if os.environ.get('RCCL_STRIP_TRACE') else 3):
+    for quiet in ((False,) if os.environ.get('RCCL_STRIP_TRACE') else (True, False)):
+        plan = Loopback(quiet)
+        r.clear()
+        for f in range(8): render_strip_frame(r, rows, plan, cams[f], f, frt)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for f in range(8, 72): render_strip_frame(r, rows, plan, cams[f], f, frt)
+        th = (time.perf_counter() - t0) / 64 * 1e3       # host time to ENQUEUE a frame (the GPU runs behind)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / 64 * 1e3
+        res[quiet] = min(res.get(quiet, 1e9), t)
+        host[quiet] = min(host.get(quiet, 1e9), th)
+if True not in res: res[True] = float("nan")
+print(("main stream = torch's current stream (" + ("a pool stream" if os.environ.get("RCCL_STRIP_OWN_STREAM") else "the legacy default stream") + "), " if os.environ.get("RCCL_STRIP_TORCH_STREAM") else "the renderer's own main stream, ") + f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}: strip {rank} of {world}: {res[True]:.3f} ms per frame without transfers, {res[False]:.3f} with the RCCL exchanges (send-to-self): exposed {res[False] - res[True]:+.3f} ms; host enqueue time per frame {host.get(True, float('nan')):.3f} / {host[False]:.3f} ms", flush=True)
+dist.destroy_process_group()
