@@ -363,10 +363,14 @@ void frt_multi_renderer_destroy(frt_multi_renderer* m) {
     }
     m->cv_post.notify_all();
     for (Strip& s : m->strips) if (s.worker.joinable()) s.worker.join();
-    for (Strip& s : m->strips) {
+    for (Strip& s : m->strips) {      // every strip idle before any strip's buffers go away (a neighbour's incoming copy reads them)
         DevGuard g(s.device);
         if (s.r) (void)frt_renderer_sync(s.r);
-        if (s.copy) { (void)hipStreamSynchronize(s.copy); (void)hipStreamDestroy(s.copy); }
+        if (s.copy) (void)hipStreamSynchronize(s.copy);
+    }
+    for (Strip& s : m->strips) {
+        DevGuard g(s.device);
+        if (s.copy) (void)hipStreamDestroy(s.copy);
         for (hipEvent_t e : {s.ev_tm, s.ev_spatial, s.ev_post, s.ev_copy_pre, s.ev_copy_mid, s.ev_copy_post, s.ev_src, s.ev_gather}) if (e) (void)hipEventDestroy(e);
         if (s.r) frt_renderer_destroy(s.r);
     }
