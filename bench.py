@@ -554,8 +554,8 @@ def main():
         roof = roofline_block(world, frame_ms, stages, px)
         par = "1 GPU, two-stream schedule"
         if world > 1:
-            par = (f"{world} work-balanced image strips {bounds}; per frame 2 halo exchanges per neighbour ({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'}): "
-                   "12 reservoir rows overlapped with the spatial stage's interior rows, 1 accumulation row posted a frame early; "
+            par = (f"{world} work-balanced image strips {bounds}; per frame ONE batched halo exchange with each neighbour ({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'}), behind T-merge and overlapped with the "
+                   "spatial stage's interior rows: 12 reservoir rows + 1 row of the previous accumulation; "
                    f"exposed transfer time {exposed_ms:.3f} ms/frame (frame loop with vs without the transfers)")
         out = {
             "metric": "Mrays/sec, 1920x1080 8-bounce Cornell Box", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
