@@ -437,6 +437,20 @@ def main():
             torch.cuda.set_stream(torch.cuda.ExternalStream(r.stream_handle(0), device=f"cuda:{local_rank}"))
         return r, ArenaRows(r, arena, staging_device=None if a.backend == "nccl" else "cpu")
 
+    if dist and world > 1 and a.backend == "nccl":
+        # RCCL creates its point-to-point communicator and stream at the first transfer. Do that NOW, before the renderer's streams exist: the HIP runtime
+        # hands out its four hardware queues in stream-creation order, and RCCL's stream then shares one with the renderer's LAST stream (the second edge
+        # stream) instead of with its main stream, where every transfer sat between T-merge and the interior launch (one-GPU rehearsal: 0.465 -> 0.436 ms per
+        # 1/8-strip frame, profiles/r4_experiments/rccl_strips.md). It also keeps the communicator's set-up out of the warm-up frames. Same pattern as the
+        # frame loop's exchange: one batch, upper neighbour first.
+        warm_s, warm_r = torch.zeros(256, device=f"cuda:{local_rank}"), torch.zeros(2, 256, device=f"cuda:{local_rank}")
+        ops = []
+        for k, peer in enumerate(p for p in (rank - 1, rank + 1) if 0 <= p < world):
+            ops += [dist.P2POp(dist.isend, warm_s, peer), dist.P2POp(dist.irecv, warm_r[k], peer)]
+        if ops:
+            for w_ in dist.batch_isend_irecv(ops):
+                w_.wait()
+        torch.cuda.synchronize()
     r, rows = make(W, H, plan)
 
     def frame_fn(rr, rws, pl, cam_list):

@@ -39,6 +39,10 @@ class Loopback(StripPlan):
 
 if os.environ.get("RCCL_STRIP_OWN_STREAM"):      # main stream = a stream of torch's pool instead of the legacy default stream
     torch.cuda.set_stream(torch.cuda.Stream())
+if not os.environ.get("RCCL_STRIP_COLD_P2P"):      # create RCCL's point-to-point communicator and stream BEFORE the renderer's streams
+    a_, b_ = torch.zeros(256, device="cuda:0"), torch.zeros(256, device="cuda:0")
+    for w_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, a_, 0), dist.P2POp(dist.irecv, b_, 0)]): w_.wait()
+    torch.cuda.synchronize()
 scene = frt.scenes.create_cornell_box()
 nbytes = frt.Renderer.arena_bytes(W, H)
 arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device="cuda:0")
@@ -65,5 +69,5 @@ for rnd in range(1 if os.environ.get('RCCL_STRIP_TRACE') else 3):
         res[quiet] = min(res.get(quiet, 1e9), t)
         host[quiet] = min(host.get(quiet, 1e9), th)
 if True not in res: res[True] = float("nan")
-print(("main stream = torch's current stream (" + ("a pool stream" if os.environ.get("RCCL_STRIP_OWN_STREAM") else "the legacy default stream") + "), " if os.environ.get("RCCL_STRIP_TORCH_STREAM") else "the renderer's own main stream, ") + f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}: strip {rank} of {world}: {res[True]:.3f} ms per frame without transfers, {res[False]:.3f} with the RCCL exchanges (send-to-self): exposed {res[False] - res[True]:+.3f} ms; host enqueue time per frame {host.get(True, float('nan')):.3f} / {host[False]:.3f} ms", flush=True)
+print(("" if not os.environ.get("RCCL_STRIP_COLD_P2P") else "RCCL's P2P stream created by the first frame's transfer, ") + ("main stream = torch's current stream (" + ("a pool stream" if os.environ.get("RCCL_STRIP_OWN_STREAM") else "the legacy default stream") + "), " if os.environ.get("RCCL_STRIP_TORCH_STREAM") else "the renderer's own main stream, ") + f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}: strip {rank} of {world}: {res[True]:.3f} ms per frame without transfers, {res[False]:.3f} with the RCCL exchanges (send-to-self): exposed {res[False] - res[True]:+.3f} ms; host enqueue time per frame {host.get(True, float('nan')):.3f} / {host[False]:.3f} ms", flush=True)
 dist.destroy_process_group()
