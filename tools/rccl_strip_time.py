@@ -43,6 +43,30 @@ if not os.environ.get("RCCL_STRIP_COLD_P2P"):      # create RCCL's point-to-poin
     a_, b_ = torch.zeros(256, device="cuda:0"), torch.zeros(256, device="cuda:0")
     for w_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, a_, 0), dist.P2POp(dist.irecv, b_, 0)]): w_.wait()
     torch.cuda.synchronize()
+_side = {}
+def frame_fake(r, access, plan, cam, frame):
+    """Diagnostic: the frame loop with the exchange replaced by the stream choreography alone (RCCL_STRIP_FAKE = record: an event recorded on the main stream
+    behind T-merge; wait: ... and a side stream made to wait for it; copy: ... and a 737 KB device copy on the side stream that the edge stream then waits for)."""
+    mode = os.environ["RCCL_STRIP_FAKE"]
+    r.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
+    if not plan.quiet:
+        if "s" not in _side:
+            _side["s"] = torch.cuda.Stream(); _side["a"] = torch.zeros(737280, dtype=torch.uint8, device="cuda:0"); _side["b"] = torch.zeros_like(_side["a"])
+        ev = torch.cuda.Event()
+        ev.record()
+        if mode in ("wait", "copy"):
+            _side["s"].wait_event(ev)
+        if mode == "copy":
+            with torch.cuda.stream(_side["s"]):
+                _side["b"].copy_(_side["a"], non_blocking=True)
+                ev2 = torch.cuda.Event(); ev2.record()
+            access.edge_stream().wait_event(ev2)
+    r.render_phases(cam, frt.PHASE_SPATIAL_INNER)
+    r.render_phases(cam, frt.PHASE_SPATIAL_EDGE)
+    r.render_phases(cam, frt.PHASE_POST)
+    r.end_frame()
+
+
 scene = frt.scenes.create_cornell_box()
 nbytes = frt.Renderer.arena_bytes(W, H)
 arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device="cuda:0")
@@ -56,18 +80,20 @@ else:
 rows = ArenaRows(r, arena)
 cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(80)]
 res, host = {}, {}
+WHAT = 'the RCCL exchanges (send-to-self)' if not os.environ.get('RCCL_STRIP_FAKE') else 'the fake exchange (' + os.environ['RCCL_STRIP_FAKE'] + ')'
+frame = frame_fake if os.environ.get('RCCL_STRIP_FAKE') else (lambda r_, a_, p_, c_, f_: render_strip_frame(r_, a_, p_, c_, f_, frt))
 for rnd in range(1 if os.environ.get('RCCL_STRIP_TRACE') else 3):
     for quiet in ((False,) if os.environ.get('RCCL_STRIP_TRACE') else (True, False)):
         plan = Loopback(quiet)
         r.clear()
-        for f in range(8): render_strip_frame(r, rows, plan, cams[f], f, frt)
+        for f in range(8): frame(r, rows, plan, cams[f], f)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for f in range(8, 72): render_strip_frame(r, rows, plan, cams[f], f, frt)
+        for f in range(8, 72): frame(r, rows, plan, cams[f], f)
         th = (time.perf_counter() - t0) / 64 * 1e3       # host time to ENQUEUE a frame (the GPU runs behind)
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / 64 * 1e3
         res[quiet] = min(res.get(quiet, 1e9), t)
         host[quiet] = min(host.get(quiet, 1e9), th)
 if True not in res: res[True] = float("nan")
-print(("" if not os.environ.get("RCCL_STRIP_COLD_P2P") else "RCCL's P2P stream created by the first frame's transfer, ") + ("main stream = torch's current stream (" + ("a pool stream" if os.environ.get("RCCL_STRIP_OWN_STREAM") else "the legacy default stream") + "), " if os.environ.get("RCCL_STRIP_TORCH_STREAM") else "the renderer's own main stream, ") + f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}: strip {rank} of {world}: {res[True]:.3f} ms per frame without transfers, {res[False]:.3f} with the RCCL exchanges (send-to-self): exposed {res[False] - res[True]:+.3f} ms; host enqueue time per frame {host.get(True, float('nan')):.3f} / {host[False]:.3f} ms", flush=True)
+print(("" if not os.environ.get("RCCL_STRIP_COLD_P2P") else "RCCL's P2P stream created by the first frame's transfer, ") + ("main stream = torch's current stream (" + ("a pool stream" if os.environ.get("RCCL_STRIP_OWN_STREAM") else "the legacy default stream") + "), " if os.environ.get("RCCL_STRIP_TORCH_STREAM") else "the renderer's own main stream, ") + f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}: strip {rank} of {world}: {res[True]:.3f} ms per frame without transfers, {res[False]:.3f} with {WHAT}: exposed {res[False] - res[True]:+.3f} ms; host enqueue time per frame {host.get(True, float('nan')):.3f} / {host[False]:.3f} ms", flush=True)
 dist.destroy_process_group()
