@@ -9,7 +9,7 @@ Metric (BASELINE.json): Mrays/s = (closest-hit + any-hit rays issued, counted on
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: one process per GPU, the frame is cut into N horizontal strips, two halo exchanges per frame over RCCL (frt.dist);
+N > 1: one process per GPU, the frame is cut into N horizontal strips, one batched halo exchange per frame and neighbour over RCCL (frt.dist);
 total work is fixed ("strong" scaling). Rank 0 prints ONE JSON line. Either launch form works: with RANK / WORLD_SIZE in the
 environment this process IS a rank; without them `--gpus N` starts its own N rank processes (fresh children, before this
 process has touched the GPU), relays rank 0's line and exits non-zero if any rank fails.

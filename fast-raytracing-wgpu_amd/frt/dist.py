@@ -8,12 +8,13 @@ horizontal strips (contiguous in row-major, so strips gather in place); the scen
   spatial   : reads temporal reservoirs within 10 px (restir_spatial.wgsl:902-921); this build runs it on 2 extra rows
               per side so that post's +-2-row radiance reads (post.wgsl:93) stay local  -> needs 12 reservoir halo rows
   post      : reads the previous accumulation within +-1 row (post.wgsl:196-199)            -> needs 1 history halo row
-Two exchanges per frame with each vertical neighbour, on different dependency chains:
+Two sets of rows per frame and vertical neighbour, on different dependency chains, travelling in ONE batch (render_strip_frame):
   "mid"  : 12 rows of temporal reservoirs (32 B/px) between T-merge and the spatial stage. This one sits on the frame-to-frame
            chain (T-merge -> spatial -> T-merge); it is overlapped with the spatial stage's INTERIOR rows, which need nothing from a
            neighbour (FRT_PHASE_SPATIAL_INNER), and only the edge rows wait for it.
-  "post" : 1 row of the previous frame's accumulation (16 B/px) for post. Posted at the start of the frame (its source is the previous
-           frame's post), waited for just before post: a whole frame of slack.
+  "post" : 1 row of the previous frame's accumulation (16 B/px) for post. Its source is the previous frame's post and its consumer this
+           frame's post, so it may travel any time in between: it rides with the "mid" rows (a batch of its own at the start of the
+           frame cost a thin strip a second RCCL launch on its chain, profiles/r4_experiments/rccl_strips.md).
 
 Moving camera (StripPlan(motion_halo=K), Renderer(motion_halo=K)): T-merge reprojects into the PREVIOUS frame's spatial
 reservoirs and G-buffer (restir.wgsl:846-900) and post fetches the previous accumulation bilinearly at the reprojected position

@@ -1,5 +1,5 @@
 """RCCL rehearsal on ONE GPU: the N > 1 frame loop of bench.py (frt.dist.render_strip_frame: arena views as send / receive buffers, the "mid"
-exchange posted behind T-merge and finished on the edge-row stream, the "post" exchange a frame ahead) over the real "nccl" backend with a
+rows and the "post" rows in one batch posted behind T-merge and finished on the edge-row stream) over the real "nccl" backend with a
 world of one rank, every transfer a send-to-self inside one batch. The image means nothing (the strip's "neighbour" is itself); what is
 checked is that the communicator comes up on cuda:0, that device-to-device point-to-point transfers of arena rows complete under the
 stream ordering the loop sets up, and that the rows arrive bit for bit. Prints one JSON line."""
