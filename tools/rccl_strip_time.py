@@ -2,7 +2,7 @@
 1080p frame over the real "nccl" backend with a world of one rank — every transfer a send-to-self of the rows a neighbour would send (same bytes, same
 stream orderings; tests/_nccl_selftest.py checks the pixels of this set-up) — against the same loop without transfers. The HIP runtime maps a process's
 streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): a strip renderer under the pipeline uses four streams itself, RCCL adds its own.
-    [GPU_MAX_HW_QUEUES=8] [RCCL_STRIP_TORCH_STREAM=1 [RCCL_STRIP_OWN_STREAM=1]] python tools/rccl_strip_time.py [rank world]
+    [GPU_MAX_HW_QUEUES=8] [RCCL_STRIP_TORCH_STREAM=1 [RCCL_STRIP_OWN_STREAM=1]] python tools/rccl_strip_time.py [rank world] [4k]
 RCCL_STRIP_TORCH_STREAM=1: the renderer is handed torch's current stream as its main stream (what bench.py did before round 4's fix)."""
 import os, sys, time
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -13,9 +13,10 @@ import torch
 import torch.distributed as dist
 import frt
 from frt.dist import StripPlan, ArenaRows, render_strip_frame, HALO_RESERVOIR, BUF_RESERVOIR, BUF_ACCUM
-rank = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-W, H = 1920, 1080
+args = [x for x in sys.argv[1:] if x != "4k"]
+rank = int(args[0]) if args else 4
+world = int(args[1]) if len(args) > 1 else 8
+W, H = (3840, 2160) if "4k" in sys.argv[1:] else (1920, 1080)
 rb, re = H * rank // world, H * (rank + 1) // world
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -95,5 +96,5 @@ for rnd in range(1 if os.environ.get('RCCL_STRIP_TRACE') else 3):
         res[quiet] = min(res.get(quiet, 1e9), t)
         host[quiet] = min(host.get(quiet, 1e9), th)
 if True not in res: res[True] = float("nan")
-print(("" if not os.environ.get("RCCL_STRIP_COLD_P2P") else "RCCL's P2P stream created by the first frame's transfer, ") + ("main stream = torch's current stream (" + ("a pool stream" if os.environ.get("RCCL_STRIP_OWN_STREAM") else "the legacy default stream") + "), " if os.environ.get("RCCL_STRIP_TORCH_STREAM") else "the renderer's own main stream, ") + f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}: strip {rank} of {world}: {res[True]:.3f} ms per frame without transfers, {res[False]:.3f} with {WHAT}: exposed {res[False] - res[True]:+.3f} ms; host enqueue time per frame {host.get(True, float('nan')):.3f} / {host[False]:.3f} ms", flush=True)
+print(("" if not os.environ.get("RCCL_STRIP_COLD_P2P") else "RCCL's P2P stream created by the first frame's transfer, ") + ("main stream = torch's current stream (" + ("a pool stream" if os.environ.get("RCCL_STRIP_OWN_STREAM") else "the legacy default stream") + "), " if os.environ.get("RCCL_STRIP_TORCH_STREAM") else "the renderer's own main stream, ") + f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}: strip {rank} of {world} of {W}x{H}: {res[True]:.3f} ms per frame without transfers, {res[False]:.3f} with {WHAT}: exposed {res[False] - res[True]:+.3f} ms; host enqueue time per frame {host.get(True, float('nan')):.3f} / {host[False]:.3f} ms", flush=True)
 dist.destroy_process_group()
