@@ -44,6 +44,20 @@ if not os.environ.get("RCCL_STRIP_COLD_P2P"):      # create RCCL's point-to-poin
     a_, b_ = torch.zeros(256, device="cuda:0"), torch.zeros(256, device="cuda:0")
     for w_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, a_, 0), dist.P2POp(dist.irecv, b_, 0)]): w_.wait()
     torch.cuda.synchronize()
+def frame_nofinish(r, access, plan, cam, frame):
+    """Diagnostic: the real RCCL batch is posted, but nothing waits for it (wrong pixels): what does POSTING it cost the main stream?"""
+    from frt.dist import start_exchange
+    r.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)
+    ex = start_exchange(access, plan, frame, None, when=("mid", "post"))
+    r.render_phases(cam, frt.PHASE_SPATIAL_INNER)
+    r.render_phases(cam, frt.PHASE_SPATIAL_EDGE)
+    r.render_phases(cam, frt.PHASE_POST)
+    r.end_frame()
+    _keep.append(ex)
+    if len(_keep) > 8: _keep.pop(0)
+_keep = []
+
+
 _side = {}
 def frame_fake(r, access, plan, cam, frame):
     """Diagnostic: the frame loop with the exchange replaced by the stream choreography alone (RCCL_STRIP_FAKE = record: an event recorded on the main stream
@@ -72,6 +86,7 @@ scene = frt.scenes.create_cornell_box()
 nbytes = frt.Renderer.arena_bytes(W, H)
 arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device="cuda:0")
 off = (-arena.data_ptr()) % 256
+_dummies = [frt.Renderer(scene, 16, 16, device=0) for _ in range(int(os.environ.get("RCCL_STRIP_DUMMY_STREAMS", "0")))]      # diagnostic: shift the stream -> hardware queue mapping (one stream each)
 if not os.environ.get("RCCL_STRIP_TORCH_STREAM"):      # (bench.py since round 4) the renderer creates its main stream itself, next to its other streams; torch is told to use it
     torch.cuda.synchronize()
     r = frt.Renderer(scene, W, H, device=0, rows=(rb, re), arena=arena.data_ptr() + off, arena_bytes=nbytes, flags=frt.FLAG_PIPELINE)
@@ -81,8 +96,9 @@ else:
 rows = ArenaRows(r, arena)
 cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(80)]
 res, host = {}, {}
+DUM = os.environ.get("RCCL_STRIP_DUMMY_STREAMS")
 WHAT = 'the RCCL exchanges (send-to-self)' if not os.environ.get('RCCL_STRIP_FAKE') else 'the fake exchange (' + os.environ['RCCL_STRIP_FAKE'] + ')'
-frame = frame_fake if os.environ.get('RCCL_STRIP_FAKE') else (lambda r_, a_, p_, c_, f_: render_strip_frame(r_, a_, p_, c_, f_, frt))
+frame = frame_nofinish if os.environ.get('RCCL_STRIP_FAKE') == 'nofinish' else frame_fake if os.environ.get('RCCL_STRIP_FAKE') else (lambda r_, a_, p_, c_, f_: render_strip_frame(r_, a_, p_, c_, f_, frt))
 for rnd in range(1 if os.environ.get('RCCL_STRIP_TRACE') else 3):
     for quiet in ((False,) if os.environ.get('RCCL_STRIP_TRACE') else (True, False)):
         plan = Loopback(quiet)
@@ -96,5 +112,5 @@ for rnd in range(1 if os.environ.get('RCCL_STRIP_TRACE') else 3):
         res[quiet] = min(res.get(quiet, 1e9), t)
         host[quiet] = min(host.get(quiet, 1e9), th)
 if True not in res: res[True] = float("nan")
-print(("" if not os.environ.get("RCCL_STRIP_COLD_P2P") else "RCCL's P2P stream created by the first frame's transfer, ") + ("main stream = torch's current stream (" + ("a pool stream" if os.environ.get("RCCL_STRIP_OWN_STREAM") else "the legacy default stream") + "), " if os.environ.get("RCCL_STRIP_TORCH_STREAM") else "the renderer's own main stream, ") + f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}: strip {rank} of {world} of {W}x{H}: {res[True]:.3f} ms per frame without transfers, {res[False]:.3f} with {WHAT}: exposed {res[False] - res[True]:+.3f} ms; host enqueue time per frame {host.get(True, float('nan')):.3f} / {host[False]:.3f} ms", flush=True)
+print((f"{DUM} dummy streams first, " if DUM else "") + ("" if not os.environ.get("RCCL_STRIP_COLD_P2P") else "RCCL's P2P stream created by the first frame's transfer, ") + ("main stream = torch's current stream (" + ("a pool stream" if os.environ.get("RCCL_STRIP_OWN_STREAM") else "the legacy default stream") + "), " if os.environ.get("RCCL_STRIP_TORCH_STREAM") else "the renderer's own main stream, ") + f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}: strip {rank} of {world} of {W}x{H}: {res[True]:.3f} ms per frame without transfers, {res[False]:.3f} with {WHAT}: exposed {res[False] - res[True]:+.3f} ms; host enqueue time per frame {host.get(True, float('nan')):.3f} / {host[False]:.3f} ms", flush=True)
 dist.destroy_process_group()
