@@ -66,9 +66,8 @@ def main():
             exchange_halos(acc, plan, f, when="pre")
             r.render_phases(cams[f], 1, max(rb - hg, 0) if a.world > 1 else 0, min(re + hg, H) if a.world > 1 else H)
             r.render_phases(cams[f], 2, rb, re)
-            exchange_halos(acc, plan, f, when="mid")
+            exchange_halos(acc, plan, f, when=("mid", "post"))      # ONE batch per frame, as frt.dist.render_strip_frame posts it: the "post" rows ride with the "mid" rows
             r.render_phases(cams[f], 4, max(rb - 2, 0), min(re + 2, H))
-            exchange_halos(acc, plan, f, when="post")
             r.render_phases(cams[f], 8, rb, re)
             r.end_frame()
         mine = torch.from_numpy(r.read_rows(7, (N - 1) % 2, rb, re).copy())
