@@ -437,7 +437,34 @@ def main():
             torch.cuda.set_stream(torch.cuda.ExternalStream(r.stream_handle(0), device=f"cuda:{local_rank}"))
         return r, ArenaRows(r, arena, staging_device=None if a.backend == "nccl" else "cpu")
 
-    if dist and world > 1 and a.backend == "nccl":
+    # The halo rows travel as grouped RCCL send / recv launches placed directly IN the renderer's streams (frt.rccl over librccl.so; torch.distributed only
+    # carries the communicator's id): torch's own point-to-point operations put eight event markers on the main stream, a hop to torch's RCCL stream and a
+    # hop back between T-merge and the edge rows (one-GPU rehearsal, 1/8 strip: 0.437 -> 0.395 ms per frame, host time per frame 0.23 -> 0.11 ms;
+    # profiles/r4_experiments/rccl_strips.md). Every rank votes: if the communicator cannot be had everywhere, every rank uses torch's operations.
+    comm = None
+    if dist and world > 1 and a.backend == "nccl" and os.environ.get("FRT_BENCH_TORCH_P2P") != "1":
+        import frt.rccl
+        ok = 1
+        try:
+            frt.rccl.lib()
+        except Exception as e:      # noqa: BLE001
+            ok = 0
+            print(f"[rank {rank}] librccl.so cannot be loaded directly ({e}); torch.distributed point-to-point operations instead", file=sys.stderr)
+        vote = torch.tensor([ok], dtype=torch.int32, device=comm_dev)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        if int(vote.item()) == 1:      # every rank can call RCCL: the communicator's creation is collective from here on
+            try:
+                comm = frt.rccl.Comm.create(rank, world, local_rank)
+            except Exception as e:      # noqa: BLE001
+                ok = 0
+                print(f"[rank {rank}] ncclCommInitRank failed ({e}); torch.distributed point-to-point operations instead", file=sys.stderr)
+            vote = torch.tensor([ok], dtype=torch.int32, device=comm_dev)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+            if int(vote.item()) != 1:
+                if comm is not None:
+                    comm.destroy()
+                comm = None
+    if dist and world > 1 and a.backend == "nccl" and comm is None:
         # RCCL creates its point-to-point communicator and stream at the first transfer. Do that NOW, before the renderer's streams exist: the HIP runtime
         # hands out its four hardware queues in stream-creation order, and RCCL's stream then shares one with the renderer's LAST stream (the second edge
         # stream) instead of with its main stream, where every transfer sat between T-merge and the interior launch (one-GPU rehearsal: 0.465 -> 0.436 ms per
@@ -456,7 +483,7 @@ def main():
     def frame_fn(rr, rws, pl, cam_list):
         if world == 1:
             return lambda f: rr.render(cam_list[f])
-        return lambda f: render_strip_frame(rr, rws, pl, cam_list[f], f, frt)
+        return lambda f: render_strip_frame(rr, rws, pl, cam_list[f], f, frt, comm=comm)
 
     frame = frame_fn(r, rows, plan, cams)
     sync = torch.cuda.synchronize
@@ -494,7 +521,7 @@ def main():
         dist.barrier(); torch.cuda.synchronize()
         tq = time.perf_counter()
         for f in range(first_extra, first_extra + nq):
-            render_strip_frame(r, rows, quiet, cams[f], f, frt)
+            render_strip_frame(r, rows, quiet, cams[f], f, frt, comm=comm)
         torch.cuda.synchronize(); dist.barrier()
         quiet_s, _ = reduce_time_rays(time.perf_counter() - tq, 0)
         exposed_ms = elapsed / a.steps * 1e3 - quiet_s / nq * 1e3
@@ -568,7 +595,7 @@ def main():
         roof = roofline_block(world, frame_ms, stages, px)
         par = "1 GPU, two-stream schedule"
         if world > 1:
-            par = (f"{world} work-balanced image strips {bounds}; per frame ONE batched halo exchange with each neighbour ({'RCCL' if a.backend == 'nccl' else 'gloo rehearsal'}), behind T-merge and overlapped with the "
+            par = (f"{world} work-balanced image strips {bounds}; per frame ONE batched halo exchange with each neighbour ({('RCCL, grouped send / recv placed in the renderer edge stream (frt.rccl)' if comm is not None else 'RCCL through torch.distributed point-to-point operations') if a.backend == 'nccl' else 'gloo rehearsal'}), behind T-merge and overlapped with the "
                    "spatial stage's interior rows: 12 reservoir rows + 1 row of the previous accumulation; "
                    f"exposed transfer time {exposed_ms:.3f} ms/frame (frame loop with vs without the transfers)")
         out = {
@@ -581,7 +608,9 @@ def main():
                        "allreduce_of_ones": allreduce_ranks, "ranks": ranks, "one_gpu_rehearsal": one_gpu,
                        "self_launched": os.environ.get("FRT_BENCH_SELF_LAUNCHED") == "1",
                        "speculated_frames": s1["speculated_frames"] - s0["speculated_frames"], "queue_overflow": s1["queue_overflow"],
-                       "exchange_exposed_ms": exposed_ms, "gather_ms": gather["ms"] if gather else None, "gather": gather},
+                       "exchange_exposed_ms": exposed_ms, "gather_ms": gather["ms"] if gather else None, "gather": gather,
+                       "exchange": (None if not dist else "frt.rccl: grouped ncclSend / ncclRecv in the renderer's edge stream" if comm is not None
+                                    else "torch.distributed batch_isend_irecv" + (" (gloo rehearsal)" if a.backend != "nccl" else ""))},
             "roofline": roof,
             "stage_ms": dict(zip(STAGES, ms)),
             "stage_ms_note": f"per-stage HIP event times of a separate instrumented pass of {n_inst} frames after the timed region (the timed region records no events)",
@@ -591,6 +620,9 @@ def main():
         if cpu:
             out["cpu_baseline"] = cpu
         emit_result(out)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.destroy()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -24,7 +24,9 @@ the "post" exchange grows to K + 1 rows. Reads beyond the halo are counted (stat
 
 `exchange_halos` is transport-agnostic: it moves `rows(...)` tensors with torch.distributed point-to-point ops
 (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" on CPU for tests). `render_strip_frame` is one frame of one rank:
-the phases and the exchanges in the order described above (what bench.py --gpus N and the multi-rank tests run).
+the phases and the exchanges in the order described above (what bench.py --gpus N and the multi-rank tests run). Given a
+`frt.rccl.Comm` it places the transfers as grouped RCCL launches directly in the renderer's streams instead (`render_strip_frame_direct`:
+no torch stream, no event per operation — the form bench.py's ranks use on a GPU node).
 """
 import numpy as np
 
@@ -158,6 +160,24 @@ def start_exchange(access, plan, frame, group=None, when="mid", serial=None):
     return _Exchange(access, dist.batch_isend_irecv(ops), recvs)
 
 
+def exchange_direct(comm, access, plan, frame, when, stream_handle, serial=None):
+    """The same exchange as ONE grouped RCCL launch (frt.rccl.Comm) IN the HIP stream `stream_handle`: the rows are read and written in place (zero-copy
+    arena views), the transfer is ordered by that stream alone — whatever the stream holds before is done before the rows leave, whatever it gets next sees
+    the rows that arrived. Returns True when something was posted."""
+    tr = []
+    for w in ((when,) if isinstance(when, str) else when):
+        tr += plan.transfers(frame, w, serial) if serial is not None else plan.transfers(frame, w)
+    if not tr:
+        return False
+    sends, recvs = [], []
+    for peer, buf, index, srows, rrows in tr:
+        sv, rv = access._view(buf, index, *srows), access._view(buf, index, *rrows)
+        sends.append((sv.data_ptr(), sv.numel(), peer))
+        recvs.append((rv.data_ptr(), rv.numel(), peer))
+    comm.exchange(sends, recvs, stream_handle)
+    return True
+
+
 def exchange_halos(access, plan, frame, group=None, when="mid"):
     """start_exchange + finish: the blocking form (CPU oracle strips; host-staged transports)."""
     ex = start_exchange(access, plan, frame, group, when)
@@ -165,8 +185,11 @@ def exchange_halos(access, plan, frame, group=None, when="mid"):
         ex.finish()
 
 
-def render_strip_frame(r, access, plan, cam, frame, frt, group=None, serial=None):
+def render_strip_frame(r, access, plan, cam, frame, frt, group=None, serial=None, comm=None):
     """One frame of one rank's strip renderer `r` (frt.Renderer on torch's current stream, buffers in `access`'s arena).
+
+    comm: a frt.rccl.Comm -> the exchanges are grouped RCCL launches placed directly IN the renderer's streams (render_strip_frame_direct below);
+    None -> torch.distributed's batched point-to-point operations, as described here.
 
     Everything a transfer touches (reservoirs, accumulation) is produced on the renderer's main stream = torch's current stream, so the
     transfers are ordered by that stream alone. ONE batch per frame (static camera): the "mid" rows (this frame's temporal reservoirs) and
@@ -175,6 +198,8 @@ def render_strip_frame(r, access, plan, cam, frame, frt, group=None, serial=None
     T-merge — put two RCCL launches with ~50 us of launch latency each on a thin strip's chain: 0.503 -> 0.43 ms per frame for a 1/8 strip
     of the 1080p frame, tools/rccl_strip_time.py.)
     With a host-staged transport (gloo rehearsal, `access.staging`) start_exchange blocks in the device-to-host copy; same order."""
+    if comm is not None:
+        return render_strip_frame_direct(r, access, plan, cam, frame, frt, comm, serial)
     pre = start_exchange(access, plan, frame, group, when="pre", serial=serial)        # behind spatial(f-1) (moving camera only)
     if pre:
         pre.finish()
@@ -187,6 +212,26 @@ def render_strip_frame(r, access, plan, cam, frame, frt, group=None, serial=None
             mid.finish()                                                # only the stream of the edge rows waits for the neighbours' rows
     r.render_phases(cam, frt.PHASE_SPATIAL_EDGE)                        # edge rows (beside the interior ones) + continuations: the main stream joins the edge stream
     r.render_phases(cam, frt.PHASE_POST)                                # ... and is thereby behind the arrival of the accumulation rows
+    r.end_frame()
+
+
+def render_strip_frame_direct(r, access, plan, cam, frame, frt, comm, serial=None):
+    """render_strip_frame with RCCL called directly on the renderer's streams (frt.rccl): no torch stream, no events per transfer.
+      "pre" rows (moving camera): a grouped launch in the MAIN stream, right before T-merge, which consumes them;
+      "mid" + "post" rows: ONE grouped launch in the EDGE stream (frt_renderer_stream(r, 2)) — ordered behind T-merge by one event — followed in that
+      stream by the edge rows' launches; the main stream joins the edge stream before the continuation launches and post (frt_renderer.hip), and is
+      thereby behind the arrival of the accumulation rows and behind the departure of everything T-merge(f+1) and post(f+1) overwrite.
+    Measured on one GPU (send-to-self, tools/rccl_strip_time.py): see profiles/r4_experiments/rccl_strips.md."""
+    import torch
+    exchange_direct(comm, access, plan, frame, "pre", r.stream_handle(0), serial)
+    r.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)        # T-merge(f)
+    h_edge = r.stream_handle(2)
+    if h_edge != r.stream_handle(0):
+        access.edge_stream().wait_stream(torch.cuda.current_stream())   # the edge stream behind T-merge (current stream = the renderer's main stream)
+    exchange_direct(comm, access, plan, frame, ("mid", "post"), h_edge)
+    r.render_phases(cam, frt.PHASE_SPATIAL_INNER)                       # interior rows beside the transfer
+    r.render_phases(cam, frt.PHASE_SPATIAL_EDGE)                        # edge rows: in the edge stream behind the transfer
+    r.render_phases(cam, frt.PHASE_POST)
     r.end_frame()
 
 

@@ -46,7 +46,10 @@ def main():
         def end_frame(self): self.r.end_frame()
         def stream_handle(self, which): return self.r.stream_handle(which)
 
-    def run(W, H, rb, re, N, stepwise):
+    import frt.rccl
+    direct = frt.rccl.Comm.create(0, 1, 0)      # RCCL called directly on the renderer's streams (frt.dist.render_strip_frame_direct): what bench.py's ranks use
+
+    def run(W, H, rb, re, N, stepwise, comm=None):
         nbytes = frt.Renderer.arena_bytes(W, H)
         arena = torch.zeros(nbytes + 256, dtype=torch.uint8, device="cuda:0")
         off = (-arena.data_ptr()) % 256
@@ -55,7 +58,7 @@ def main():
         rows = ArenaRows(r, arena)
         plan = Loopback(H, rb, re)
         for f in range(N):
-            render_strip_frame(Stepwise(r) if stepwise else r, rows, plan, frt.CameraController().build_uniform(W / H, f, 2), f, frt)
+            render_strip_frame(Stepwise(r) if stepwise else r, rows, plan, frt.CameraController().build_uniform(W / H, f, 2), f, frt, comm=comm)
             if stepwise:
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
@@ -77,7 +80,13 @@ def main():
         same = all(got[k][rb:re].tobytes() == want[k][rb:re].tobytes() for k in got)      # the strip's own rows of every stage's output
         report[name] = {"rows_arrive": bool(ok_rows), "async_equals_stepwise": bool(same), "speculated_frames": st["speculated_frames"]}
         ok &= bool(ok_rows) and bool(same)
+        # the same frames with the transfers as grouped RCCL launches IN the renderer's edge stream: same rows, same pixels as the stepwise reference
+        ok_rows_d, got_d, _, _ = run(W, H, rb, re, N, stepwise=False, comm=direct)
+        same_d = all(got_d[k][rb:re].tobytes() == want[k][rb:re].tobytes() for k in got_d)
+        report[name]["direct_rows_arrive"] = bool(ok_rows_d); report[name]["direct_equals_stepwise"] = bool(same_d)
+        ok &= bool(ok_rows_d) and bool(same_d)
     report["ok"] = bool(ok)
+    direct.destroy()
     print(json.dumps(report))
     dist.destroy_process_group()
 

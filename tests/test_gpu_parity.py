@@ -526,6 +526,9 @@ def test_rccl_loopback_rehearsal_on_one_gpu(gpu):
     assert res["ok"] and res["nccl"], res
     # a strip too thin for interior rows: its edge launches are ordered behind the transfer on the edge stream
     assert res["thin"]["rows_arrive"] and res["thin"]["async_equals_stepwise"], res
+    # ... and with RCCL called directly on the renderer's streams (frt.rccl: one grouped launch in the edge stream, no torch stream, no events)
+    for k in ("interior", "thin"):
+        assert res[k]["direct_rows_arrive"] and res[k]["direct_equals_stepwise"], res
 
 
 def test_bench_self_launch_rehearsal_on_one_gpu(gpu):

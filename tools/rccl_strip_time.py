@@ -97,8 +97,12 @@ rows = ArenaRows(r, arena)
 cams = [frt.CameraController().build_uniform(W / H, f, 2) for f in range(80)]
 res, host = {}, {}
 DUM = os.environ.get("RCCL_STRIP_DUMMY_STREAMS")
-WHAT = 'the RCCL exchanges (send-to-self)' if not os.environ.get('RCCL_STRIP_FAKE') else 'the fake exchange (' + os.environ['RCCL_STRIP_FAKE'] + ')'
-frame = frame_nofinish if os.environ.get('RCCL_STRIP_FAKE') == 'nofinish' else frame_fake if os.environ.get('RCCL_STRIP_FAKE') else (lambda r_, a_, p_, c_, f_: render_strip_frame(r_, a_, p_, c_, f_, frt))
+WHAT = 'the RCCL exchanges (send-to-self), RCCL called directly on the edge stream' if os.environ.get('RCCL_STRIP_DIRECT') else 'the RCCL exchanges (send-to-self)' if not os.environ.get('RCCL_STRIP_FAKE') else 'the fake exchange (' + os.environ['RCCL_STRIP_FAKE'] + ')'
+_comm = None
+if os.environ.get('RCCL_STRIP_DIRECT'):      # RCCL called directly on the renderer's streams (frt.rccl), as bench.py's ranks do
+    import frt.rccl
+    _comm = frt.rccl.Comm.create(0, 1, 0)
+frame = frame_nofinish if os.environ.get('RCCL_STRIP_FAKE') == 'nofinish' else frame_fake if os.environ.get('RCCL_STRIP_FAKE') else (lambda r_, a_, p_, c_, f_: render_strip_frame(r_, a_, p_, c_, f_, frt, comm=_comm))
 for rnd in range(1 if os.environ.get('RCCL_STRIP_TRACE') else 3):
     for quiet in ((False,) if os.environ.get('RCCL_STRIP_TRACE') else (True, False)):
         plan = Loopback(quiet)
