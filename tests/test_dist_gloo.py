@@ -97,3 +97,51 @@ def test_pre_rows_are_gated_on_frames_rendered_not_on_frame_count(frt):
     assert p.transfers(0, "post", serial=3) == [] and len(p.transfers(2, "post", serial=3)) == 2
     assert len(p.transfers(5, "pre")) == 2            # a counter that never restarts: serial defaults to frame
     assert StripPlan(96, 3, 1).transfers(4, "pre", serial=4) == []      # static camera: no motion halo, no "pre" rows
+
+
+def test_direct_rccl_binding_loads_and_orders_its_transfers():
+    """frt/rccl.py (RCCL called directly on the renderer's streams; what bench.py's ranks use on a GPU node): the library torch ships exports what the
+    binding calls, a unique id is 128 bytes, and frt.dist.exchange_direct posts every send and every receive of a frame's ("mid", "post") transfers in ONE
+    group, sends and receives of a peer in the same order on both sides (a grouped ncclSend / ncclRecv pair matches by order per peer). No GPU needed:
+    the communicator is a recorder."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fast-raytracing-wgpu_amd"))
+    import torch
+    import frt.rccl as R
+    from frt.dist import StripPlan, exchange_direct, BUF_RESERVOIR, BUF_ACCUM, HALO_RESERVOIR
+    L = R.lib()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+        assert hasattr(L, name), name
+    assert len(R.unique_id()) == R.NCCL_UNIQUE_ID_BYTES == 128
+
+    W, H, world = 64, 96, 3
+    bpp = {BUF_RESERVOIR: 32, BUF_ACCUM: 16}
+
+    class Rows:          # the arena as frt.dist.ArenaRows exposes it: one tensor per (buffer, index), full-frame pitch
+        def __init__(self):
+            self.t = {}
+        def _view(self, buf, index, y0, y1):
+            t = self.t.setdefault((buf, index), torch.zeros(H * W * bpp[buf], dtype=torch.uint8))
+            return t[y0 * W * bpp[buf]:y1 * W * bpp[buf]]
+
+    class Recorder:
+        def __init__(self): self.calls = []
+        def exchange(self, sends, recvs, stream): self.calls.append((sends, recvs, stream))
+
+    posted = {}
+    for rank in range(world):
+        rec, rows = Recorder(), Rows()
+        plan = StripPlan(H, world, rank)
+        assert exchange_direct(rec, rows, plan, 0, "pre", 7) is False and rec.calls == []            # static camera: no "pre" rows
+        assert exchange_direct(rec, rows, plan, 2, ("mid", "post"), 7) is True
+        assert len(rec.calls) == 1 and rec.calls[0][2] == 7                                           # ONE group, in the stream it was given
+        sends, recvs, _ = rec.calls[0]
+        peers = [p for p in (rank - 1, rank + 1) if 0 <= p < world]
+        assert [p for _, _, p in sends] == peers + peers == [p for _, _, p in recvs]                   # "mid" rows of every neighbour, then "post" rows
+        n_mid, n_post = HALO_RESERVOIR * W * 32, 1 * W * 16
+        assert [n for _, n, _ in sends] == [n_mid] * len(peers) + [n_post] * len(peers) == [n for _, n, _ in recvs]
+        posted[rank] = (sends, recvs)
+    for a in range(world - 1):       # what a sends to a + 1, a + 1 receives from a: same sizes in the same order
+        to_b = [n for _, n, p in posted[a][0] if p == a + 1]
+        from_a = [n for _, n, p in posted[a + 1][1] if p == a]
+        assert to_b == from_a and len(to_b) == 2
