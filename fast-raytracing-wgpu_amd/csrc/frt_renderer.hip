@@ -1187,6 +1187,14 @@ int frt_renderer_fence(frt_renderer* r) {
     FRT_DEVICE(r);
     return fence_ahead(r);
 }
+int frt_renderer_order_edge_stream(frt_renderer* r) {
+    if (!r) return fail(FRT_ERR_INVALID_ARG, "order_edge_stream: null");
+    if (!r->edge) return FRT_OK;
+    if (!r->frame_open || !r->tm_done) return fail(FRT_ERR_STATE, "order_edge_stream: call it after FRT_PHASE_TEMPORAL of the open frame");
+    FRT_DEVICE(r);
+    HIP_TRY(hipStreamWaitEvent(r->edge, r->ev_tm[r->serial & 1u], 0));
+    return FRT_OK;
+}
 void* frt_renderer_stream(const frt_renderer* r, int which) {
     if (!r) return nullptr;
     if (which == 1 && r->ahead) return (void*)r->ahead;

@@ -113,6 +113,7 @@ SYMBOLS = {
     "frt_renderer_render_jittered": (C.c_int, [_P, C.POINTER(CameraUniform), C.c_float, C.c_float]),
     "frt_renderer_sync": (C.c_int, [_P]),
     "frt_renderer_fence": (C.c_int, [_P]),
+    "frt_renderer_order_edge_stream": (C.c_int, [_P]),
     "frt_renderer_stream": (_P, [_P, C.c_int]),
     "frt_renderer_frame_count": (_U32, [_P]),
     "frt_renderer_reset": (C.c_int, [_P]),

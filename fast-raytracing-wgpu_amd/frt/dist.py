@@ -227,7 +227,10 @@ def render_strip_frame_direct(r, access, plan, cam, frame, frt, comm, serial=Non
     r.render_phases(cam, frt.PHASE_GBUFFER | frt.PHASE_TEMPORAL)        # T-merge(f)
     h_edge = r.stream_handle(2)
     if h_edge != r.stream_handle(0):
-        access.edge_stream().wait_stream(torch.cuda.current_stream())   # the edge stream behind T-merge (current stream = the renderer's main stream)
+        if hasattr(r, "order_edge_stream"):
+            r.order_edge_stream()                                       # the edge stream behind T-merge, with the event the renderer recorded there anyway
+        else:
+            access.edge_stream().wait_stream(torch.cuda.current_stream())   # (a wrapper without the call: one more event on the main stream)
     exchange_direct(comm, access, plan, frame, ("mid", "post"), h_edge)
     r.render_phases(cam, frt.PHASE_SPATIAL_INNER)                       # interior rows beside the transfer
     r.render_phases(cam, frt.PHASE_SPATIAL_EDGE)                        # edge rows: in the edge stream behind the transfer

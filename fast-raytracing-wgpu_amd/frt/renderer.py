@@ -59,6 +59,10 @@ class Renderer:
         """Order the renderer's stream behind its internal second stream (no host wait); call before using buffer_info pointers."""
         check(lib().frt_renderer_fence(self._h))
 
+    def order_edge_stream(self):
+        """The edge stream behind the open frame's T-merge, now (frt_renderer_order_edge_stream): for transfers placed in that stream."""
+        check(lib().frt_renderer_order_edge_stream(self._h))
+
     def stream_handle(self, which=0):
         return lib().frt_renderer_stream(self._h, which) or 0
 

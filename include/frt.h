@@ -262,6 +262,10 @@ int frt_renderer_sync(frt_renderer* r);                       /* block until enq
  * its internal second stream (FRT_FLAG_PIPELINE). Call before touching buffers from frt_renderer_buffer_info on the caller's stream
  * (halo exchange, zero-copy views). */
 int frt_renderer_fence(frt_renderer* r);
+/* Orders the edge stream (frt_renderer_stream(r, 2)) behind the open frame's T-merge, now, with the event the renderer recorded behind T-merge anyway
+ * (FRT_PHASE_SPATIAL_EDGE does the same later): for a caller that places a transfer of the T-merge's output IN that stream, in front of the edge rows'
+ * launches (frt/rccl.py). Call after frt_renderer_render_phases(... TEMPORAL). A renderer without an edge stream: no-op. */
+int frt_renderer_order_edge_stream(frt_renderer* r);
 /* The streams the renderer enqueues on: which = 0 the main stream (opts->stream: T-merge, spatial, post — everything a halo exchange
  * reads), 1 the second stream of FRT_FLAG_PIPELINE (G-buffer + T-trace of the next frame), 2 the stream on which a strip renderer
  * under FRT_FLAG_PIPELINE launches FRT_PHASE_SPATIAL_EDGE's pixel kernels: a caller that receives halo rows orders THAT stream behind
