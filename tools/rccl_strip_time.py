@@ -2,8 +2,15 @@
 1080p frame over the real "nccl" backend with a world of one rank — every transfer a send-to-self of the rows a neighbour would send (same bytes, same
 stream orderings; tests/_nccl_selftest.py checks the pixels of this set-up) — against the same loop without transfers. The HIP runtime maps a process's
 streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): a strip renderer under the pipeline uses four streams itself, RCCL adds its own.
-    [GPU_MAX_HW_QUEUES=8] [RCCL_STRIP_TORCH_STREAM=1 [RCCL_STRIP_OWN_STREAM=1]] python tools/rccl_strip_time.py [rank world] [4k]
-RCCL_STRIP_TORCH_STREAM=1: the renderer is handed torch's current stream as its main stream (what bench.py did before round 4's fix)."""
+    RCCL_STRIP_DIRECT=1 python tools/rccl_strip_time.py [rank world] [4k]      # what bench.py's ranks run: RCCL called directly in the renderer's edge stream (frt.rccl)
+    python tools/rccl_strip_time.py [rank world] [4k]                          # the fallback: torch.distributed's batched point-to-point operations
+Knobs that reproduce the states profiles/r4_experiments/rccl_strips.md walks through:
+    RCCL_STRIP_TORCH_STREAM=1 [RCCL_STRIP_OWN_STREAM=1]   the renderer is handed torch's current stream as its main stream (bench.py before round 4's fix)
+    RCCL_STRIP_COLD_P2P=1                                 torch's RCCL point-to-point stream is created by the first frame's transfer, not before the renderer
+    RCCL_STRIP_FAKE=record | wait | copy | nofinish       the exchange replaced by parts of its stream choreography (diagnostics)
+    RCCL_STRIP_DUMMY_STREAMS=k                            k streams created first (shifts the stream -> hardware queue mapping)
+    RCCL_STRIP_TRACE=1                                    a short run for rocprofv3 --kernel-trace (tools/timeline_all.py prints the timeline)
+    GPU_MAX_HW_QUEUES=n, NCCL_NCHANNELS_PER_PEER=n        the runtime's / RCCL's own knobs"""
 import os, sys, time
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
