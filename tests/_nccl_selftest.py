@@ -35,6 +35,8 @@ def main():
                 return [(0, BUF_RESERVOIR, 0, (rb, rb + HALO_RESERVOIR), (re, re + HALO_RESERVOIR))]
             if when == "post" and frame > 0:
                 return [(0, BUF_ACCUM, (frame - 1) % 2, (rb, rb + 1), (re, re + 1))]
+            if when == "pre" and frame > 0:      # (a moving camera's exchange: the previous frame's spatial reservoirs, consumed by T-merge on the MAIN stream)
+                return [(0, BUF_RESERVOIR, 1, (rb, rb + 4), (re, re + 4))]
             return []
 
     scene = frt.scenes.create_cornell_box()
@@ -78,11 +80,12 @@ def main():
         ok_rows, got, st, _ = run(W, H, rb, re, N, stepwise=False)
         _, want, _, _ = run(W, H, rb, re, N, stepwise=True)
         same = all(got[k][rb:re].tobytes() == want[k][rb:re].tobytes() for k in got)      # the strip's own rows of every stage's output
+        same &= got["res1"][re:re + 4].tobytes() == want["res1"][re:re + 4].tobytes() and bool(want["res1"][re:re + 4].any())      # the "pre" rows landed, and when they should
         report[name] = {"rows_arrive": bool(ok_rows), "async_equals_stepwise": bool(same), "speculated_frames": st["speculated_frames"]}
         ok &= bool(ok_rows) and bool(same)
         # the same frames with the transfers as grouped RCCL launches IN the renderer's edge stream: same rows, same pixels as the stepwise reference
         ok_rows_d, got_d, _, _ = run(W, H, rb, re, N, stepwise=False, comm=direct)
-        same_d = all(got_d[k][rb:re].tobytes() == want[k][rb:re].tobytes() for k in got_d)
+        same_d = all(got_d[k][rb:re].tobytes() == want[k][rb:re].tobytes() for k in got_d) and got_d["res1"][re:re + 4].tobytes() == want["res1"][re:re + 4].tobytes()
         report[name]["direct_rows_arrive"] = bool(ok_rows_d); report[name]["direct_equals_stepwise"] = bool(same_d)
         ok &= bool(ok_rows_d) and bool(same_d)
     report["ok"] = bool(ok)
